@@ -1,0 +1,427 @@
+// api.cpp — the C ABI of libgcnspmm.so (see include/gcn_spmm.h for the contract and
+// the reference interfaces each entry point replaces).
+#include "../../include/gcn_spmm.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <vector>
+
+#include "reorder.h"
+#include "spmm_kernels.h"
+
+#define GCN_VERSION_STR "0.1.0"
+
+struct gcn_spmm_plan {
+  int32_t m, n, nnz, T, nchunks;
+  int* chunk_row;     // device [nchunks]
+  float* ws;          // device partial slab, grow-only
+  size_t ws_bytes;
+  int cu_count;
+  int device;
+};
+
+namespace {
+
+std::mutex g_mu;
+
+int cu_count_cached() {
+  static int cached[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return -1;
+  if (dev < 0 || dev >= 64) return -1;
+  if (cached[dev] > 0) return cached[dev];
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
+  cached[dev] = prop.multiProcessorCount;
+  return cached[dev];
+}
+
+// chunk size: multiple of 64, aims at >= 16 chunks per resident wave (8 blocks x 4
+// waves per CU) so that the static XCD-range schedule stays balanced, capped at 512.
+int auto_chunk_nnz(long long nnz, int cu) {
+  if (cu <= 0) cu = 256;
+  const long long waves = (long long)cu * 32;
+  long long t = nnz / (waves * 16);
+  t = (t / 64) * 64;
+  if (t < 64) t = 64;
+  if (t > 512) t = 512;
+  return (int)t;
+}
+
+int ensure_ws(gcn_spmm_plan* p, int k) {
+  const size_t need = gcn_spmm_plan_workspace_bytes(p, k);
+  if (need <= p->ws_bytes) return GCN_OK;
+  if (p->ws) { (void)hipFree(p->ws); p->ws = nullptr; p->ws_bytes = 0; }
+  if (hipMalloc((void**)&p->ws, need) != hipSuccess) return GCN_ERR_ALLOC;
+  p->ws_bytes = need;
+  return GCN_OK;
+}
+
+void die(const char* what, hipError_t e) {
+  std::fprintf(stderr, "libgcnspmm: %s failed: %s\n", what, hipGetErrorString(e));
+  std::abort();
+}
+
+bool verbose() {
+  const char* v = std::getenv("GCN_AMD_VERBOSE");
+  return v && v[0] && v[0] != '0';
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* gcn_status_string(int s) {
+  switch (s) {
+    case GCN_OK: return "ok";
+    case GCN_ERR_INVALID_ARG: return "invalid argument";
+    case GCN_ERR_HIP: return "HIP runtime error";
+    case GCN_ERR_NO_DEVICE: return "no HIP device";
+    case GCN_ERR_CAPACITY: return "caller buffer too small";
+    case GCN_ERR_ALLOC: return "device allocation failed";
+    default: return "unknown status";
+  }
+}
+
+const char* gcn_version(void) { return GCN_VERSION_STR; }
+
+int gcn_device_cu_count(void) { return cu_count_cached(); }
+
+// ---------------------------------------------------------------------------
+int gcn_spmm_plan_create(gcn_spmm_plan_t** out, const int32_t* rowptr_dev, int32_t m, int32_t n,
+                         int32_t nnz, int32_t chunk_nnz, void* stream) {
+  if (!out || m < 0 || n < 0 || nnz < 0 || (m > 0 && !rowptr_dev)) return GCN_ERR_INVALID_ARG;
+  if (chunk_nnz < 0 || (chunk_nnz % 64) != 0) return GCN_ERR_INVALID_ARG;
+  const int cu = cu_count_cached();
+  if (cu <= 0) return GCN_ERR_NO_DEVICE;
+  gcn_spmm_plan* p = new (std::nothrow) gcn_spmm_plan();
+  if (!p) return GCN_ERR_ALLOC;
+  p->m = m; p->n = n; p->nnz = nnz;
+  p->T = chunk_nnz ? chunk_nnz : auto_chunk_nnz(nnz, cu);
+  p->nchunks = (int)(((long long)nnz + p->T - 1) / p->T);
+  p->chunk_row = nullptr; p->ws = nullptr; p->ws_bytes = 0; p->cu_count = cu;
+  (void)hipGetDevice(&p->device);
+  if (p->nchunks > 0) {
+    if (hipMalloc((void**)&p->chunk_row, sizeof(int) * (size_t)p->nchunks) != hipSuccess) {
+      delete p; return GCN_ERR_ALLOC;
+    }
+    if (gcn::launch_plan_chunk_rows(rowptr_dev, m, p->T, p->nchunks, p->chunk_row,
+                                    (hipStream_t)stream) != hipSuccess) {
+      (void)hipFree(p->chunk_row); delete p; return GCN_ERR_HIP;
+    }
+  }
+  *out = p;
+  return GCN_OK;
+}
+
+int gcn_spmm_plan_destroy(gcn_spmm_plan_t* p) {
+  if (!p) return GCN_OK;
+  if (p->chunk_row) (void)hipFree(p->chunk_row);
+  if (p->ws) (void)hipFree(p->ws);
+  delete p;
+  return GCN_OK;
+}
+
+int32_t gcn_spmm_plan_num_chunks(const gcn_spmm_plan_t* p) { return p ? p->nchunks : -1; }
+int32_t gcn_spmm_plan_chunk_nnz(const gcn_spmm_plan_t* p) { return p ? p->T : -1; }
+size_t gcn_spmm_plan_workspace_bytes(const gcn_spmm_plan_t* p, int32_t k) {
+  if (!p || k <= 0) return 0;
+  return sizeof(float) * 2 * (size_t)(p->nchunks > 0 ? p->nchunks : 1) * (size_t)k;
+}
+
+int gcn_spmm_csr_f32_bias_relu(gcn_spmm_plan_t* p, const int32_t* rowptr, const int32_t* col,
+                               const float* val, const float* B, float* C, const float* bias,
+                               int32_t relu, int32_t k, void* stream) {
+  if (!p || k < 0) return GCN_ERR_INVALID_ARG;
+  if (p->m == 0 || k == 0) return GCN_OK;
+  if (!C || !rowptr || (p->nnz > 0 && (!col || !val || !B))) return GCN_ERR_INVALID_ARG;
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    const int st = ensure_ws(p, k);
+    if (st != GCN_OK) return st;
+  }
+  gcn::SpmmArgs a;
+  a.rowptr = rowptr; a.col = col; a.val = val; a.B = B; a.C = C; a.P = p->ws;
+  a.chunk_row = p->chunk_row; a.bias = bias; a.relu = relu ? 1 : 0;
+  a.nchunks = p->nchunks; a.T = p->T; a.m = p->m; a.nnz = p->nnz; a.k = k;
+  a.nnz_dev = nullptr; a.nchunks_grid = p->nchunks;
+  return gcn::launch_spmm(a, p->cu_count, (hipStream_t)stream) == hipSuccess ? GCN_OK : GCN_ERR_HIP;
+}
+
+int gcn_spmm_csr_f32(gcn_spmm_plan_t* p, const int32_t* rowptr, const int32_t* col,
+                     const float* val, const float* B, float* C, int32_t k, void* stream) {
+  return gcn_spmm_csr_f32_bias_relu(p, rowptr, col, val, B, C, nullptr, 0, k, stream);
+}
+
+// One-shot: the schedule is recomputed on the device every call (a few µs: one
+// binary search per chunk) into a process-wide scratch plan, so there is no cache
+// that could go stale when the caller reuses device addresses.
+int gcn_spmm_csr_f32_oneshot(const int32_t* rowptr, const int32_t* col, const float* val,
+                             const float* B, float* C, int32_t m, int32_t n, int32_t nnz,
+                             int32_t k, void* stream) {
+  static gcn_spmm_plan scratch = {};
+  static size_t chunk_cap = 0;
+  if (m < 0 || n < 0 || nnz < 0 || k < 0) return GCN_ERR_INVALID_ARG;
+  const int cu = cu_count_cached();
+  if (cu <= 0) return GCN_ERR_NO_DEVICE;
+  std::lock_guard<std::mutex> lk(g_mu);
+  gcn_spmm_plan* p = &scratch;
+  p->m = m; p->n = n; p->nnz = nnz; p->cu_count = cu;
+  p->T = auto_chunk_nnz(nnz, cu);
+  p->nchunks = (int)(((long long)nnz + p->T - 1) / p->T);
+  if ((size_t)p->nchunks > chunk_cap) {
+    if (p->chunk_row) (void)hipFree(p->chunk_row);
+    p->chunk_row = nullptr; chunk_cap = 0;
+    if (hipMalloc((void**)&p->chunk_row, sizeof(int) * (size_t)p->nchunks) != hipSuccess)
+      return GCN_ERR_ALLOC;
+    chunk_cap = (size_t)p->nchunks;
+  }
+  if (m == 0 || k == 0) return GCN_OK;
+  if (gcn::launch_plan_chunk_rows(rowptr, m, p->T, p->nchunks, p->chunk_row,
+                                  (hipStream_t)stream) != hipSuccess) return GCN_ERR_HIP;
+  const int st = ensure_ws(p, k);
+  if (st != GCN_OK) return st;
+  gcn::SpmmArgs a;
+  a.rowptr = rowptr; a.col = col; a.val = val; a.B = B; a.C = C; a.P = p->ws;
+  a.chunk_row = p->chunk_row; a.bias = nullptr; a.relu = 0;
+  a.nchunks = p->nchunks; a.T = p->T; a.m = m; a.nnz = nnz; a.k = k;
+  a.nnz_dev = nullptr; a.nchunks_grid = p->nchunks;
+  return gcn::launch_spmm(a, cu, (hipStream_t)stream) == hipSuccess ? GCN_OK : GCN_ERR_HIP;
+}
+
+int gcn_gather_rows_f32(float* dst, const float* src, const int32_t* idx, int32_t nrows, int32_t k,
+                        void* stream) {
+  if (nrows < 0 || k < 0) return GCN_ERR_INVALID_ARG;
+  if (nrows == 0 || k == 0) return GCN_OK;
+  if (!dst || !src || !idx || dst == src) return GCN_ERR_INVALID_ARG;
+  return gcn::launch_gather_rows(dst, src, idx, nrows, k, (hipStream_t)stream) == hipSuccess
+             ? GCN_OK : GCN_ERR_HIP;
+}
+
+// ---------------------------------------------------------------------------
+// host reorderers
+// ---------------------------------------------------------------------------
+static bool csr_ok(const int32_t* rowptr, const int32_t* col, int32_t n, int32_t nnz) {
+  if (n < 0 || nnz < 0 || !rowptr || (nnz > 0 && !col)) return false;
+  if (rowptr[0] != 0 || rowptr[n] != nnz) return false;
+  for (int32_t i = 0; i < n; ++i) if (rowptr[i + 1] < rowptr[i]) return false;
+  for (int32_t e = 0; e < nnz; ++e) if (col[e] < 0 || col[e] >= n) return false;
+  return true;
+}
+
+int gcn_order_deg(const int32_t* rowptr, const int32_t* col, int32_t n, int32_t nnz, int32_t which,
+                  int32_t desc, int64_t* rank_out) {
+  if (!rank_out || which < 0 || which > 2 || !csr_ok(rowptr, col, n, nnz)) return GCN_ERR_INVALID_ARG;
+  gcn::reorder::Csr g{rowptr, col, n, nnz};
+  auto r = gcn::reorder::order_deg(g, (gcn::reorder::DegKind)which, desc != 0);
+  for (int32_t i = 0; i < n; ++i) rank_out[i] = (int64_t)r[i];
+  return GCN_OK;
+}
+
+int gcn_order_rcm(const int32_t* rowptr, const int32_t* col, int32_t n, int32_t nnz,
+                  int32_t directed, int64_t* rank_out) {
+  if (!rank_out || !csr_ok(rowptr, col, n, nnz)) return GCN_ERR_INVALID_ARG;
+  gcn::reorder::Csr g{rowptr, col, n, nnz};
+  auto r = gcn::reorder::order_rcm(g, directed != 0);
+  for (int32_t i = 0; i < n; ++i) rank_out[i] = (int64_t)r[i];
+  return GCN_OK;
+}
+
+int gcn_order_gorder(const int32_t* rowptr, const int32_t* col, int32_t n, int32_t nnz,
+                     int32_t window, int64_t* rank_out) {
+  if (!rank_out || window < 1 || !csr_ok(rowptr, col, n, nnz)) return GCN_ERR_INVALID_ARG;
+  gcn::reorder::Csr g{rowptr, col, n, nnz};
+  bool ok = true;
+  auto r = gcn::reorder::order_gorder_complete(g, (gcn::reorder::u64)window, &ok);
+  if (!ok) return GCN_ERR_INVALID_ARG;
+  for (int32_t i = 0; i < n; ++i) rank_out[i] = (int64_t)r[i];
+  return GCN_OK;
+}
+
+int gcn_csr_apply_rank(int32_t* rowptr, int32_t* col, float* vals, int32_t n, int32_t nnz,
+                       const int64_t* rank, int32_t* vomp_out) {
+  if (!rank || !vals || !csr_ok(rowptr, col, n, nnz)) return GCN_ERR_INVALID_ARG;
+  std::vector<gcn::reorder::u64> r(n);
+  std::vector<char> hit(n, 0);
+  for (int32_t i = 0; i < n; ++i) {
+    if (rank[i] < 0 || rank[i] >= n || hit[rank[i]]) return GCN_ERR_INVALID_ARG;   // bijection
+    hit[rank[i]] = 1;
+    r[i] = (gcn::reorder::u64)rank[i];
+  }
+  gcn::reorder::csr_apply_rank(rowptr, col, vals, n, nnz, r.data());
+  if (vomp_out) for (int32_t i = 0; i < n; ++i) vomp_out[rank[i]] = i;
+  return GCN_OK;
+}
+
+// ---------------------------------------------------------------------------
+// drop-in symbols: renumber.so
+// ---------------------------------------------------------------------------
+static void apply_and_emit(int* rowPtr, int* col, float* vals, int* vomp, int n, int nnz,
+                           const std::vector<gcn::reorder::u64>& rank) {
+  gcn::reorder::csr_apply_rank(rowPtr, col, vals, n, nnz, rank.data());
+  for (int i = 0; i < n; ++i) vomp[rank[i]] = i;     // C ABI returns new -> old
+}
+
+static void check_csr_or_die(const char* fn, int* rowPtr, int* col, int n, int nnz) {
+  if (!csr_ok(rowPtr, col, n, nnz)) {
+    std::fprintf(stderr, "libgcnspmm: %s: malformed CSR input (n=%d nnz=%d)\n", fn, n, nnz);
+    std::abort();
+  }
+}
+
+void dfs(int* rowPtr, int* col, float* vals, int* vomp, int m, int n, int nnz) {
+  (void)m;
+  check_csr_or_die("dfs", rowPtr, col, n, nnz);
+  gcn::reorder::Csr g{rowPtr, col, n, nnz};
+  apply_and_emit(rowPtr, col, vals, vomp, n, nnz, gcn::reorder::order_dfs(g));
+}
+
+void gorder(int* rowPtr, int* col, float* vals, int* vomp, int m, int n, int nnz) {
+  check_csr_or_die("gorder", rowPtr, col, m, nnz);
+  (void)n;
+  gcn::reorder::Csr g{rowPtr, col, m, nnz};
+  bool ok = true;
+  auto rank = gcn::reorder::order_gorder_complete(g, 3, &ok);      // window 3: renumber.cu:176
+  if (!ok) {
+    std::fprintf(stderr, "libgcnspmm: gorder: graph has isolated vertices in the heap index "
+                         "range; the reference's behaviour is undefined for it\n");
+    std::abort();
+  }
+  apply_and_emit(rowPtr, col, vals, vomp, m, nnz, rank);
+}
+
+void perm_apply(int* rowPtr, int* col, float* vals, int* vomp, int m, int n, int nnz) {
+  (void)m;
+  check_csr_or_die("perm_apply", rowPtr, col, n, nnz);
+  std::vector<gcn::reorder::u64> rank(n, (gcn::reorder::u64)n);
+  for (int v = 0; v < n; ++v) {
+    const int old = vomp[v];
+    if (old < 0 || old >= n || rank[old] != (gcn::reorder::u64)n) {       // renumber.cu:251
+      std::fprintf(stderr, "libgcnspmm: perm_apply: vomp is not a permutation\n");
+      std::abort();
+    }
+    rank[old] = v;
+  }
+  gcn::reorder::csr_apply_rank(rowPtr, col, vals, n, nnz, rank.data());
+}
+
+void rabbit(int* rowPtr, int* col, float* vals, int* vomp, int m, int n, int nnz) {
+  check_csr_or_die("rabbit", rowPtr, col, n, nnz);
+  gcn::reorder::Csr g{rowPtr, col, n, nnz};
+  auto vo = gcn::reorder::order_rabbit_vomp(g, verbose());
+  for (int i = 0; i < n; ++i) vomp[i] = vo[i];
+  perm_apply(rowPtr, col, vals, vomp, m, n, nnz);                 // renumber.cu:521
+}
+
+// ---------------------------------------------------------------------------
+// drop-in symbols: tile.so / flexspmm.so
+//
+// Packed layout written by csr2tile into the caller's buffers (gcn6.py:334-339;
+// after the call gcn6 shrinks seg_rowPtr to 9*n_segs and segVoMap to 8*n_segs
+// ints and copies everything to the device, gcn6.py:353-366):
+//   n_segs[0]      = nnz / 9                      (so 9*n_segs <= nnz capacity)
+//   seg_rowPtr     = rowPtr[0..m]                 (needs m+1 <= 9*n_segs)
+//   segVoMap       = chunk_row[0..nchunks)        (needs nchunks <= 8*n_segs)
+//   segNzCV[0..nnz)      = column indices, int32 bit patterns (exact for any n,
+//                          unlike the reference's float(col), tile.cu:67)
+//   segNzCV[nnz..2nnz)   = values
+//   grouped_tailSeg / next_seg: 256 zeros (never 257 entries — defect D2)
+// The chunk size T is a pure function of n_segs (auto_chunk_nnz(9*n_segs, 256)),
+// so flexspmm() can recover the whole schedule from its scalar arguments; the
+// exact nnz is read on the device from seg_rowPtr[m].
+// ---------------------------------------------------------------------------
+static int dropin_T(int n_segs) { return auto_chunk_nnz(9LL * n_segs, 256); }
+
+void csr2tile(int* rowPtr, int* colIdx, float* vals, int m, int n, int nnz, int* vo_mp,
+              int* segVoMap, int* seg_rowPtr, float* segNzCV, int* grouped_tailSeg, int* next_seg,
+              int tm, int* n_segs) {
+  (void)n; (void)vo_mp;
+  if (tm != 8) {
+    std::fprintf(stderr, "libgcnspmm: csr2tile: tm must be 8 (got %d)\n", tm);
+    std::abort();
+  }
+  check_csr_or_die("csr2tile", rowPtr, colIdx, m, nnz);
+  const int ns = nnz / 9;
+  const int T = dropin_T(ns);
+  const int nchunks = (int)(((long long)nnz + T - 1) / T);
+  if (m + 1 > 9 * ns || nchunks > 8 * ns) {
+    std::fprintf(stderr, "libgcnspmm: csr2tile: graph too sparse to pack into the caller's "
+                         "buffers (m=%d nnz=%d); need nnz >= m+10\n", m, nnz);
+    std::abort();
+  }
+  std::memcpy(seg_rowPtr, rowPtr, sizeof(int) * (size_t)(m + 1));
+  for (int i = m + 1; i < 9 * ns; ++i) seg_rowPtr[i] = nnz;
+  // chunk_row[c] = row holding non-zero c*T (first row for c = 0)
+  int r = 0;
+  for (int c = 0; c < nchunks; ++c) {
+    const long long target = (long long)c * T;
+    while (r < m && rowPtr[r + 1] <= target) ++r;
+    segVoMap[c] = (c == 0) ? 0 : r;
+  }
+  for (int i = nchunks; i < 8 * ns; ++i) segVoMap[i] = 0;
+  std::memcpy(segNzCV, colIdx, sizeof(int) * (size_t)nnz);
+  std::memcpy(segNzCV + nnz, vals, sizeof(float) * (size_t)nnz);
+  for (int i = 0; i < 256; ++i) { grouped_tailSeg[i] = 0; next_seg[i] = 0; }
+  n_segs[0] = ns;
+}
+
+void flexspmm(int* seg_rowPtr, float* segNzCV, int* segVoMap, int* grouped_tailSeg, int* next_seg,
+              int m, int n, int k, int n_segs, float* B, float* C) {
+  (void)grouped_tailSeg; (void)next_seg; (void)n;
+  static gcn_spmm_plan scratch = {};
+  if (m <= 0 || k <= 0) return;
+  const int cu = cu_count_cached();
+  if (cu <= 0) { std::fprintf(stderr, "libgcnspmm: flexspmm: no HIP device\n"); std::abort(); }
+  const int T = dropin_T(n_segs);
+  const long long nnz_ub = 9LL * n_segs + 8;
+  const int nchunks_ub = (int)((nnz_ub + T - 1) / T);
+  std::lock_guard<std::mutex> lk(g_mu);
+  scratch.nchunks = nchunks_ub;
+  if (ensure_ws(&scratch, k) != GCN_OK) die("flexspmm workspace", hipErrorOutOfMemory);
+  gcn::SpmmArgs a;
+  a.rowptr = seg_rowPtr;
+  a.col = reinterpret_cast<const int*>(segNzCV);
+  a.val = nullptr;                       // = segNzCV + nnz, resolved on the device
+  a.B = B; a.C = C; a.P = scratch.ws; a.chunk_row = segVoMap; a.bias = nullptr; a.relu = 0;
+  a.nchunks = 0; a.T = T; a.m = m; a.nnz = 0; a.k = k;
+  a.nnz_dev = seg_rowPtr + m;            // exact nnz lives in rowPtr[m]
+  a.nchunks_grid = nchunks_ub;
+  const hipError_t e = gcn::launch_spmm(a, cu, (hipStream_t) nullptr);   // legacy default stream
+  if (e != hipSuccess) die("flexspmm launch", e);
+}
+
+// ---------------------------------------------------------------------------
+// drop-in symbols: permutate.so / cuspmm.so
+// ---------------------------------------------------------------------------
+void permutate(float* B, int* voMp, int* labels, int m, int n, int k) {
+  (void)labels; (void)m;                 // labels are NOT permuted: permutate.cu:17,35
+  if (n <= 0 || k <= 0) return;
+  float* shadow = nullptr;
+  const size_t bytes = sizeof(float) * (size_t)n * (size_t)k;
+  hipError_t e = hipMalloc((void**)&shadow, bytes);
+  if (e != hipSuccess) die("permutate hipMalloc", e);
+  e = gcn::launch_gather_rows(shadow, B, voMp, n, k, nullptr);
+  if (e != hipSuccess) die("permutate gather", e);
+  e = hipMemcpyAsync(B, shadow, bytes, hipMemcpyDeviceToDevice, nullptr);
+  if (e != hipSuccess) die("permutate copy-back", e);
+  e = hipStreamSynchronize(nullptr);     // the reference synchronises too (permutate.cu:56)
+  if (e != hipSuccess) die("permutate sync", e);
+  (void)hipFree(shadow);
+}
+
+void cuspmm(float* rowPtr, int* col, float* vals, float* X, float* C, int m, int n, int nnz,
+            int dim) {
+  const int st = gcn_spmm_csr_f32_oneshot(reinterpret_cast<const int32_t*>(rowPtr), col, vals, X,
+                                          C, m, n, nnz, dim, nullptr);
+  if (st != GCN_OK) {
+    std::fprintf(stderr, "libgcnspmm: cuspmm failed: %s\n", gcn_status_string(st));
+    std::abort();
+  }
+}
+
+}  // extern "C"

@@ -1,0 +1,544 @@
+// Host-side vertex reorderers for the GCN SpMM path — degree, reverse
+// Cuthill-McKee, Gorder (RCM∘Gorder, window w), DFS and Rabbit — plus the CSR
+// rewrite that applies an ordering.
+//
+// These are preprocessing steps (run once per graph on the host); the contract
+// is that the integer vectors they return are BIT-EXACT with the reference
+// (guohaoqiang/gcn @ v1).  The code below is written against CSR directly (the
+// reference materialises a 16 B/edge edge list and virtual Adjlist classes —
+// edgelist.cuh:8-44, adjlist.cuh:16-117); every place where the reference's
+// tie-breaking or traversal order is observable is cited.
+#include "reorder.h"
+
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <cstdio>
+#include <map>
+#include <ranges>
+#include <utility>
+
+namespace gcn {
+namespace reorder {
+
+namespace {
+
+// ---- degrees --------------------------------------------------------------
+// One directed edge per stored CSR entry, self-loops included (edgelist.cuh:16-25);
+// out = row length, in = column count, total = in + out (edgelist.cu:79-102).
+void degrees(const Csr& g, std::vector<u64>& out, std::vector<u64>& in) {
+  out.assign(g.n, 0);
+  in.assign(g.n, 0);
+  for (int64_t u = 0; u < g.n; ++u) out[u] = (u64)(g.rowptr[u + 1] - g.rowptr[u]);
+  for (int64_t e = 0; e < g.nnz; ++e) ++in[g.col[e]];
+}
+
+// rank[node] = position of node when sorted by (degree asc|desc, node id asc)
+// — order_deg.cu:8-13 comparators, :19-39 rank_from_deg.  The key is a strict
+// total order, so the sort algorithm is free.
+std::vector<u64> rank_by_degree(const std::vector<u64>& deg, bool desc) {
+  const size_t n = deg.size();
+  std::vector<u64> ids(n);
+  for (size_t i = 0; i < n; ++i) ids[i] = i;
+  if (desc)
+    std::sort(ids.begin(), ids.end(), [&](u64 a, u64 b) {
+      return deg[a] > deg[b] || (deg[a] == deg[b] && a < b); });
+  else
+    std::sort(ids.begin(), ids.end(), [&](u64 a, u64 b) {
+      return deg[a] < deg[b] || (deg[a] == deg[b] && a < b); });
+  std::vector<u64> rank(n);
+  for (size_t i = 0; i < n; ++i) rank[ids[i]] = i;
+  return rank;
+}
+
+// ---- relabelled adjacency ---------------------------------------------------
+// Compact adjacency in the numbering `rank` with every neighbour list sorted
+// ascending (adjlist.cu:69-87).  kind: 'D' out-lists (adjlist.cu:127-150),
+// 'U' both directions merged into one list per vertex (adjlist.cu:94-121),
+// 'B' out-lists in [0,n) and in-lists in [n,2n) (adjlist.cu:157-187).
+struct Adj {
+  int64_t n = 0;
+  std::vector<u64> off;   // cumulative degrees
+  std::vector<u64> nb;    // neighbours
+  const u64* begin(u64 slot) const { return nb.data() + off[slot]; }
+  const u64* end(u64 slot) const { return nb.data() + off[slot + 1]; }
+  u64 deg(u64 slot) const { return off[slot + 1] - off[slot]; }
+};
+
+Adj build_adj(const Csr& g, const std::vector<u64>& rank, char kind) {
+  Adj a;
+  a.n = g.n;
+  const int64_t slots = (kind == 'B') ? 2 * g.n : g.n;
+  std::vector<u64> cnt(slots, 0);
+  for (int64_t u = 0; u < g.n; ++u) {
+    const u64 ru = rank[u];
+    for (int32_t e = g.rowptr[u]; e < g.rowptr[u + 1]; ++e) {
+      const u64 rv = rank[g.col[e]];
+      ++cnt[ru];
+      if (kind == 'U') ++cnt[rv];
+      if (kind == 'B') ++cnt[rv + g.n];
+    }
+  }
+  a.off.assign(slots + 1, 0);
+  for (int64_t s = 0; s < slots; ++s) a.off[s + 1] = a.off[s] + cnt[s];
+  a.nb.assign(a.off[slots], 0);
+  std::fill(cnt.begin(), cnt.end(), 0);
+  for (int64_t u = 0; u < g.n; ++u) {
+    const u64 ru = rank[u];
+    for (int32_t e = g.rowptr[u]; e < g.rowptr[u + 1]; ++e) {
+      const u64 rv = rank[g.col[e]];
+      a.nb[a.off[ru] + cnt[ru]++] = rv;
+      if (kind == 'U') a.nb[a.off[rv] + cnt[rv]++] = ru;
+      if (kind == 'B') a.nb[a.off[rv + g.n] + cnt[rv + g.n]++] = ru;
+    }
+  }
+  for (int64_t s = 0; s < slots; ++s)
+    std::sort(a.nb.begin() + a.off[s], a.nb.begin() + a.off[s + 1]);
+  return a;
+}
+
+// BFS over all components: start at vertex 0, restart at the next unplaced INDEX,
+// neighbours in (sorted) list order — algo_bfs.cu:11-39.  Returns order[i] = vertex.
+std::vector<u64> bfs_order(const Adj& a) {
+  std::vector<char> placed(a.n, 0);
+  std::vector<u64> order;
+  order.reserve(a.n);
+  size_t head = 0;
+  for (int64_t s = 0; s < a.n; ++s) {
+    if (placed[s]) continue;
+    placed[s] = 1;
+    order.push_back(s);
+    while (head < order.size()) {
+      const u64 w = order[head++];
+      for (const u64* v = a.begin(w); v != a.end(w); ++v) {
+        if (placed[*v]) continue;
+        placed[*v] = 1;
+        order.push_back(*v);
+      }
+    }
+  }
+  return order;
+}
+
+// ---- the Gorder priority structure ------------------------------------------
+// Behavioural restatement of the reference's UnitHeap (unitheap.cu:16-217): a
+// doubly linked list of vertices kept in key-descending order with per-key
+// (first,last) bucket markers and LAZY negative updates that are only applied to
+// the current top (DecreaseTop, halving the pending amount each time).  Every
+// tie-break below is observable in the final order, so the operations follow the
+// reference's semantics one for one.
+class LazyBuckets {
+ public:
+  explicit LazyBuckets(u64 n)
+      : huge((u64)std::sqrt((double)n)), none_(n + 2),
+        key_(n, kInf), pend_(n, kInf), prev_(n, n + 2), next_(n, n + 2) {}
+
+  static constexpr int kInf = INT_MAX / 2;
+  u64 huge;            // hub cut-off, sqrt(n) truncated (unitheap.cu:19)
+  size_t live = 0;
+  u64 top = 0;
+
+  void insert(u64 v, int key) {          // unitheap.cu:23-28
+    key_[v] = key;
+    pend_[v] = -key;
+    ++live;
+  }
+
+  // unitheap.cu:30-62 — sorts the indices 0..live-1 (the reference's silent
+  // assumption: every inserted vertex has an index below `live`).
+  void build() {
+    std::vector<u64> g(live);
+    for (size_t i = 0; i < live; ++i) g[i] = i;
+    std::sort(g.begin(), g.end(), [&](u64 a, u64 b) {
+      return key_[a] > key_[b] || (key_[a] == key_[b] && a < b); });
+    top = g[0];
+    int cur = key_[top];
+    bucket(cur).first = top;
+    for (size_t i = 0; i < g.size(); ++i) {
+      const u64 v = g[i];
+      prev_[v] = i > 0 ? g[i - 1] : none_;
+      next_[v] = i + 1 < g.size() ? g[i + 1] : none_;
+      if (key_[v] != cur) {
+        bucket(cur).last = g[i - 1];
+        bucket(key_[v]).first = v;
+        cur = key_[v];
+      }
+    }
+    bucket(cur).last = g.back();
+  }
+
+  u64 extract_max() {                    // unitheap.cu:82-95
+    u64 t;
+    do {
+      t = top;
+      if (pend_[top] < 0) decrease_top();
+    } while (top != t);
+    remove(top);
+    return t;
+  }
+
+  void remove(u64 v) {                   // unitheap.cu:152-170
+    pend_[v] = kInf;
+    const u64 p = prev_[v], nx = next_[v];
+    if (p != none_) next_[p] = nx;
+    if (nx != none_) prev_[nx] = p;
+    unbucket(v, nx, p);
+    if (top == v) top = nx;
+    prev_[v] = next_[v] = none_;
+    --live;
+  }
+
+  // returns false on the reference's "negative" abort condition
+  bool lazy_add(u64 v, int up) {         // unitheap.cu:177-185
+    if (pend_[v] == kInf) return true;
+    if (pend_[v] == 0 && up > 0) {
+      increment(v);
+    } else {
+      pend_[v] += up;
+      if (-pend_[v] > key_[v]) return false;
+    }
+    return true;
+  }
+
+  bool has_index_gap() const { return false; }
+  u64 none() const { return none_; }
+
+ private:
+  struct Bucket { u64 first, last; };
+  u64 none_;
+  std::vector<int> key_, pend_;
+  std::vector<u64> prev_, next_;
+  std::vector<Bucket> buckets_;
+
+  Bucket& bucket(int key) {
+    if ((size_t)key >= buckets_.size()) buckets_.resize((size_t)key + 64, Bucket{none_, none_});
+    return buckets_[key];
+  }
+
+  void unbucket(u64 v, u64 nx, u64 p) {  // unitheap.cu:68-76 (note: the first test
+    Bucket& b = bucket(key_[v]);         // does not look at v itself)
+    if (b.first == b.last) b.first = b.last = none_;
+    else if (v == b.first) b.first = nx;
+    else if (v == b.last) b.last = p;
+  }
+
+  void decrease_top() {                  // unitheap.cu:98-149
+    const u64 nx = next_[top];
+    if (nx == none_) return;
+    const int key = key_[top];
+    const int leftover = pend_[top] / 2;
+    const int new_key = key + pend_[top] - leftover;
+    if (new_key >= key_[nx]) return;
+    pend_[top] = leftover;
+
+    u64 tail = bucket(key).last;
+    u64 after = next_[tail];
+    while (after != none_ && key_[after] >= new_key) {
+      tail = bucket(key_[after]).last;
+      after = next_[tail];
+    }
+    prev_[nx] = none_;
+    prev_[top] = tail;
+    next_[top] = after;
+    next_[tail] = top;
+    if (after != none_) prev_[after] = top;
+
+    unbucket(top, nx, none_);
+    key_[top] = new_key;
+    Bucket& nb = bucket(new_key);
+    nb.last = top;
+    if (nb.first == none_) nb.first = top;
+    top = nx;
+  }
+
+  void increment(u64 v) {                // unitheap.cu:187-217
+    const u64 head = bucket(key_[v]).first;
+    const u64 p = prev_[v], nx = next_[v];
+    if (head != v) {
+      next_[p] = nx;
+      if (nx != none_) prev_[nx] = p;
+      const u64 before = prev_[head];
+      prev_[v] = before;
+      next_[v] = head;
+      prev_[head] = v;
+      if (before != none_) next_[before] = v;
+    }
+    unbucket(v, nx, p);
+    const int key = ++key_[v];
+    Bucket& b = bucket(key);
+    b.last = v;
+    if (b.first == none_) {
+      b.first = v;
+      if (key > key_[top]) top = v;
+    }
+  }
+};
+
+// order_gorder.cu:88-143.  `b` holds out-lists in slots [0,n) and in-lists in [n,2n).
+bool slide_window(const Adj& b, LazyBuckets& h, u64 incoming, u64 outgoing) {
+  const u64 n = (u64)b.n;
+  const u64* op = b.begin(outgoing + n);
+  const u64* oe = b.end(outgoing + n);
+  const u64* np = b.begin(incoming + n);
+  const u64* ne = b.end(incoming + n);
+  bool ok = true;
+
+  if (outgoing == incoming) {
+    op = oe;                                        // no vertex leaves the window
+  } else if (b.deg(outgoing) <= h.huge) {
+    for (const u64* c = b.begin(outgoing); c != b.end(outgoing); ++c) ok &= h.lazy_add(*c, -1);
+  }
+
+  // parents of exactly one of the two vertices (sorted-list symmetric difference),
+  // hubs (out-degree > sqrt n) skipped
+  std::vector<u64> leaving, entering;
+  while (true) {
+    bool take_new;
+    if (op >= oe) {
+      if (np >= ne) break;
+      take_new = true;
+    } else if (np < ne) {
+      if (*np == *op) { ++op; ++np; continue; }
+      take_new = *np < *op;
+    } else {
+      take_new = false;
+    }
+    if (take_new) { if (b.deg(*np) <= h.huge) entering.push_back(*np); ++np; }
+    else          { if (b.deg(*op) <= h.huge) leaving.push_back(*op);  ++op; }
+  }
+
+  for (u64 p : leaving) {
+    ok &= h.lazy_add(p, -1);
+    for (const u64* s = b.begin(p); s != b.end(p); ++s)
+      if (*s != outgoing) ok &= h.lazy_add(*s, -1);
+  }
+  if (b.deg(incoming) <= h.huge)
+    for (const u64* c = b.begin(incoming); c != b.end(incoming); ++c) ok &= h.lazy_add(*c, +1);
+  for (u64 p : entering) {
+    ok &= h.lazy_add(p, +1);
+    for (const u64* s = b.begin(p); s != b.end(p); ++s)
+      if (*s != incoming) ok &= h.lazy_add(*s, +1);
+  }
+  return ok;
+}
+
+// order_gorder.cu:35-84; returns rank (in the numbering of `b`), ok=false if the
+// reference would have aborted or run into undefined behaviour.
+std::vector<u64> gorder_rank(const Adj& b, u64 window, bool* ok) {
+  const u64 n = (u64)b.n;
+  *ok = true;
+  std::vector<u64> order;
+  order.reserve(n);
+  LazyBuckets heap(n);
+  std::vector<u64> isolated;
+  for (u64 u = 0; u < n; ++u) {
+    if (b.deg(u) + b.deg(u + n) == 0) isolated.push_back(u);
+    else heap.insert(u, (int)b.deg(u + n));          // keyed by IN-degree
+  }
+  // the reference sorts indices 0..heapsize-1: only defined when no isolated
+  // vertex has an index below heapsize (SURVEY §8a "replicate, don't fix")
+  for (u64 u : isolated) if (u < heap.live) { *ok = false; return {}; }
+  if (heap.live == 0) {
+    std::vector<u64> rank(n);
+    for (u64 i = 0; i < n; ++i) rank[i] = i;
+    return rank;
+  }
+  heap.build();
+  const u64 hub = heap.top;
+  order.push_back(hub);
+  heap.remove(hub);
+  *ok &= slide_window(b, heap, hub, hub);
+  while (heap.live > 0 && *ok) {
+    const u64 v = heap.extract_max();
+    if (v >= n) { *ok = false; break; }
+    order.push_back(v);
+    u64 old = v;
+    if (order.size() > window) old = order[order.size() - window - 1];
+    *ok &= slide_window(b, heap, v, old);
+  }
+  if (!*ok) return {};
+  order.insert(order.end(), isolated.begin(), isolated.end());
+  std::vector<u64> rank(n);
+  for (u64 i = 0; i < n; ++i) rank[order[i]] = i;   // tools.cu:31-46
+  return rank;
+}
+
+}  // namespace
+
+// ---- public orderings ---------------------------------------------------------
+
+std::vector<u64> order_deg(const Csr& g, DegKind which, bool desc) {
+  std::vector<u64> out, in;
+  degrees(g, out, in);
+  if (which == DEG_OUT) return rank_by_degree(out, desc);       // order_deg.cu:46-50
+  if (which == DEG_IN) return rank_by_degree(in, desc);         // order_deg.cu:52-56
+  for (int64_t u = 0; u < g.n; ++u) out[u] += in[u];            // order_deg.cu:41-45
+  return rank_by_degree(out, desc);
+}
+
+// order_rcm.cu:15-33: degree-ASC relabel, BFS, reverse.
+std::vector<u64> order_rcm(const Csr& g, bool directed) {
+  const std::vector<u64> rdeg = order_deg(g, DEG_TOTAL, false);
+  const Adj a = build_adj(g, rdeg, directed ? 'D' : 'U');
+  const std::vector<u64> order = bfs_order(a);
+  std::vector<u64> pos(g.n);
+  for (int64_t i = 0; i < g.n; ++i) pos[order[i]] = i;
+  std::vector<u64> rank(g.n);
+  for (int64_t u = 0; u < g.n; ++u) rank[u] = (u64)g.n - 1 - pos[rdeg[u]];
+  return rank;
+}
+
+// order_gorder.cu:13-31
+std::vector<u64> order_gorder_complete(const Csr& g, u64 window, bool* ok) {
+  const std::vector<u64> rrcm = order_rcm(g, true);
+  const Adj b = build_adj(g, rrcm, 'B');
+  const std::vector<u64> rgo = gorder_rank(b, window, ok);
+  if (!*ok) return {};
+  std::vector<u64> rank(g.n);
+  for (int64_t u = 0; u < g.n; ++u) rank[u] = rgo[rrcm[u]];
+  return rank;
+}
+
+// renumber.cu:23-95: iterative pre-order DFS, first tree rooted at vertex 0, next
+// roots in index order, neighbours in stored CSR order.
+std::vector<u64> order_dfs(const Csr& g) {
+  const int64_t n = g.n;
+  std::vector<u64> rank(n, 0);
+  std::vector<char> seen(n, 0);
+  std::vector<std::pair<int32_t, int32_t>> stack;   // (next edge, end edge)
+  u64 next_id = 0;
+  for (int64_t root = 0; root < n; ++root) {
+    if (seen[root]) continue;
+    seen[root] = 1;
+    rank[root] = next_id++;
+    stack.push_back({g.rowptr[root], g.rowptr[root + 1]});
+    while (!stack.empty()) {
+      auto& top = stack.back();
+      while (top.first < top.second && seen[g.col[top.first]]) ++top.first;
+      if (top.first >= top.second) { stack.pop_back(); continue; }
+      const int32_t v = g.col[top.first++];
+      seen[v] = 1;
+      rank[v] = next_id++;
+      stack.push_back({g.rowptr[v], g.rowptr[v + 1]});
+    }
+  }
+  return rank;
+}
+
+// renumber.cu:319-520 (opt_iterative = true, hub grouping off, shyness 1).
+std::vector<int32_t> order_rabbit_vomp(const Csr& g, bool verbose) {
+  const int n = (int)g.n;
+  struct Vtx {
+    std::map<int, int> w;   // neighbour -> merged edge count (unit weights)
+    int deg = 0;
+    int round = 0;
+    int tree = -1;          // dendrogram node id owned by this vertex, -1 = merged away
+  };
+  std::vector<Vtx> V(n);
+  // dendrogram: node v in [0,n) is leaf v; node n+u is the cluster created when u was merged
+  std::vector<int> lch(2 * (size_t)n, -1), rch(2 * (size_t)n, -1);
+  std::vector<unsigned int> cur(n), nxt;
+  long long n_edges = 0;
+
+  // undirected simple graph, self-loops dropped; a vertex's degree is taken right
+  // after ITS row has been scanned (renumber.cu:382-398) — reverse edges inserted
+  // later by higher-numbered rows are not counted, exactly as in the reference.
+  for (int v = 0; v < n; ++v) {
+    for (int32_t e = g.rowptr[v]; e < g.rowptr[v + 1]; ++e) {
+      const int d = g.col[e];
+      if (d == v) continue;
+      V[v].w[d] = 1;
+      V[d].w[v] = 1;
+    }
+    V[v].deg = (int)V[v].w.size();
+    n_edges += V[v].deg;
+    V[v].tree = v;
+    cur[v] = v;
+  }
+  const double two_m_inv = 1.0 / double(2 * (int)n_edges);   // int arithmetic as renumber.cu:402
+
+  for (int round = 1; !cur.empty(); ++round) {
+    // sort by CURRENT degree only: not a total order, so the permutation of equal
+    // keys is whatever libstdc++'s introsort produces — same call as renumber.cu:408
+    std::ranges::sort(cur, std::ranges::less(), [&](auto i) { return V[i].deg; });
+    if (verbose) std::printf("Rabbit round %2d, n elts %zd\n", round, cur.size());
+    for (auto u : cur) {
+      Vtx& uo = V[u];
+      if (uo.round == round) continue;
+      double best = -1;
+      int v = -1;
+      const double dv_2m = uo.deg * two_m_inv;
+      for (auto [d, w] : uo.w) {                       // key order, strict > (renumber.cu:14-20,423)
+        const double dq = w - V[d].deg * dv_2m;
+        if (dq > best) { best = dq; v = d; }
+      }
+      if (best <= 0) continue;
+      Vtx& vo = V[v];
+      vo.deg += uo.deg;
+      for (auto [d, w] : uo.w) {
+        if (d == v) continue;
+        vo.w[d] += w;
+        auto& dm = V[d].w;
+        auto it = dm.find((int)u);
+        if (it == dm.end()) continue;
+        dm[v] += it->second;
+        dm.erase((int)u);
+      }
+      vo.w.erase((int)u);
+      lch[(size_t)n + u] = vo.tree;                    // (target's tree, merged tree)
+      rch[(size_t)n + u] = uo.tree;
+      uo.tree = -1;
+      vo.tree = n + (int)u;
+      if (vo.round == round) continue;
+      vo.round = round;
+      nxt.push_back(v);
+    }
+    std::swap(cur, nxt);
+    nxt.clear();
+  }
+
+  // leaves of every surviving dendrogram, roots in vertex-index order, left before right
+  std::vector<int32_t> vomp;
+  vomp.reserve(n);
+  std::vector<int> st;
+  int n_comm = 0;
+  for (int v = 0; v < n; ++v) {
+    if (V[v].tree < 0) continue;
+    ++n_comm;
+    st.push_back(V[v].tree);
+    while (!st.empty()) {
+      const int t = st.back();
+      st.pop_back();
+      if (lch[t] >= 0) { st.push_back(rch[t]); st.push_back(lch[t]); }
+      else vomp.push_back(t);
+    }
+  }
+  if (verbose) std::printf("Rabbit found %d communities, edges %lld\n", n_comm, n_edges);
+  return vomp;
+}
+
+// renumber.cu:190-217 / :244-278: rows moved to their new index, columns relabelled,
+// each row sorted by new column with the values carried along (same sort call and
+// element type as the reference so that duplicate columns, if any, permute alike).
+void csr_apply_rank(int32_t* rowptr, int32_t* col, float* vals, int64_t n, int64_t nnz,
+                    const u64* rank) {
+  std::vector<int32_t> nrow(n + 1, 0), ncol(nnz);
+  std::vector<float> nval(nnz);
+  for (int64_t u = 0; u < n; ++u) nrow[rank[u] + 1] = rowptr[u + 1] - rowptr[u];
+  for (int64_t i = 0; i < n; ++i) nrow[i + 1] += nrow[i];
+  std::vector<std::pair<float, unsigned int>> row;
+  for (int64_t u = 0; u < n; ++u) {
+    row.clear();
+    for (int32_t e = rowptr[u]; e < rowptr[u + 1]; ++e)
+      row.emplace_back(vals[e], (unsigned int)rank[col[e]]);
+    std::ranges::sort(row, std::ranges::less(), [](auto& p) { return p.second; });
+    int32_t o = nrow[rank[u]];
+    for (auto& [val, c] : row) { ncol[o] = (int32_t)c; nval[o++] = val; }
+  }
+  std::copy(nrow.begin(), nrow.end(), rowptr);
+  std::copy(ncol.begin(), ncol.end(), col);
+  std::copy(nval.begin(), nval.end(), vals);
+}
+
+}  // namespace reorder
+}  // namespace gcn

@@ -1,0 +1,34 @@
+// Internal interface between the C-ABI layer (api.cpp) and the device code
+// (spmm_kernels.hip).  Not installed; the public contract is include/gcn_spmm.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gcn {
+
+struct SpmmArgs {
+  const int*   rowptr;     // [m+1] device
+  const int*   col;        // [nnz] device
+  const float* val;        // [nnz] device
+  const float* B;          // [n x k] device, row-major, ld = k
+  float*       C;          // [m x k] device, row-major, ld = k
+  float*       P;          // partial slab [2*nchunks x k] device
+  const int*   chunk_row;  // [nchunks] device
+  const float* bias;       // [k] or nullptr
+  int relu;
+  int nchunks, T, m, nnz, k;
+  // drop-in mode (flexspmm symbol): nnz is only known on the device (nnz_dev =
+  // &rowptr[m]); the kernels then derive nchunks and the value pointer themselves
+  // and the host sizes its grids with the upper bound nchunks_grid.
+  const int* nnz_dev;
+  int nchunks_grid;
+};
+
+hipError_t launch_plan_chunk_rows(const int* rowptr, int m, int T, int nchunks,
+                                  int* chunk_row, hipStream_t s);
+hipError_t launch_spmm(const SpmmArgs& a, int cu_count, hipStream_t s);
+hipError_t launch_gather_rows(float* dst, const float* src, const int* idx, int nrows, int k,
+                              hipStream_t s);
+int pick_vec(int k, const void* B, const void* C, const void* P);
+
+}  // namespace gcn

@@ -1,0 +1,359 @@
+// spmm_kernels.hip — hand-written gfx950 (CDNA4, wave64) kernels for the GCN
+// aggregation SpMM  C[m x k] = A[m x n, CSR fp32] * B[n x k]  (row-major B, C).
+//
+// Replaces the five CUDA kernels of the reference's flexspmm.cu:17-498 and the
+// cuSPARSE call of cuspmm.cu:57-61.  It is NOT a translation of either: the
+// reference walks 8-row "tile segs" with 4/8 lanes per row and fp32 atomics on
+// split rows; this file uses an equal-nnz chunk schedule with a wavefront-level
+// segmented sum and a deterministic fix-up pass:
+//
+//   * the nnz stream is cut into chunks of T non-zeros (T multiple of 64); one
+//     wave64 owns one chunk at a time (persistent grid, XCD-aware chunk ranges);
+//   * the wave loads 64 (col,val) pairs with one coalesced load each, then walks
+//     them with v_readlane (col/val become SGPRs), issuing U whole-row gathers
+//     of B back to back: one global_load per non-zero covers the full feature
+//     row (64 lanes x VEC floats = 256/512/1024 B contiguous), so every HBM /
+//     Infinity-Cache request is a full line and U*VEC*256 B are in flight per wave;
+//   * rows are summed in registers in CSR order; a row that ends inside the
+//     chunk is stored with one coalesced row store (no atomics, C need not be
+//     zeroed); the (at most two) row pieces that stick out of the chunk go to a
+//     partial slab P and are added in chunk order by spmm_fixup_kernel, so the
+//     result is bitwise reproducible and independent of the launch geometry.
+//
+// Roofline: HBM/cache-bandwidth bound (0.49 flop/B); algorithmic bytes per
+// non-zero = 8 + 4k.  MFMA is deliberately not used: fp32 MFMA
+// peak equals the fp32 VALU peak on gfx950 and the contraction is a gather.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "spmm_kernels.h"
+
+namespace gcn {
+
+template <int VEC> struct VecOf;
+template <> struct VecOf<1> { typedef float  type; };
+template <> struct VecOf<2> { typedef float2 type; };
+template <> struct VecOf<4> { typedef float4 type; };
+
+template <int VEC>
+__device__ __forceinline__ void load_vec(const float* p, float (&out)[VEC]) {
+  typedef typename VecOf<VEC>::type V;
+  V v = *reinterpret_cast<const V*>(p);
+  const float* f = reinterpret_cast<const float*>(&v);
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) out[i] = f[i];
+}
+
+template <int VEC>
+__device__ __forceinline__ void store_vec(float* p, const float (&in)[VEC]) {
+  typedef typename VecOf<VEC>::type V;
+  V v;
+  float* f = reinterpret_cast<float*>(&v);
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) f[i] = in[i];
+  *reinterpret_cast<V*>(p) = v;
+}
+
+__device__ __forceinline__ int sgpr(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// ---------------------------------------------------------------------------
+// plan kernel: chunk_row[c] = the row that contains non-zero c*T, i.e. the r with
+// rowptr[r] <= c*T < rowptr[r+1];  chunk_row[0] = 0 so that chunk 0 also emits
+// leading empty rows.
+// ---------------------------------------------------------------------------
+__global__ void plan_chunk_rows_kernel(const int* __restrict__ rowptr, int m, int T,
+                                       int nchunks, int* __restrict__ chunk_row) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nchunks) return;
+  if (c == 0) { chunk_row[0] = 0; return; }
+  const long long target = (long long)c * T;
+  // first index i in [0, m] with rowptr[i] > target
+  int lo = 0, hi = m + 1;
+  while (lo < hi) {
+    int mid = (lo + hi) >> 1;
+    if ((long long)rowptr[mid] > target) hi = mid; else lo = mid + 1;
+  }
+  chunk_row[c] = lo - 1;
+}
+
+// ---------------------------------------------------------------------------
+// main kernel
+// ---------------------------------------------------------------------------
+template <int VEC, int U, bool EPI>
+__global__ void __launch_bounds__(256)
+spmm_chunk_kernel(const int* __restrict__ g_rowptr, const int* __restrict__ g_col,
+                  const float* __restrict__ g_val, const float* __restrict__ g_B,
+                  float* __restrict__ g_C, float* __restrict__ g_P,
+                  const int* __restrict__ g_chunk_row, const float* __restrict__ g_bias,
+                  const int* __restrict__ g_nnz_dev,
+                  int relu, int nchunks, int T, int m, int nnz, int kk) {
+  // drop-in (flexspmm) mode: the host does not know nnz; it lives in rowptr[m] and
+  // the values follow the column indices in one buffer (api.cpp, csr2tile layout)
+  if (g_nnz_dev) {
+    nnz = *g_nnz_dev;
+    nchunks = (int)(((long long)nnz + T - 1) / T);
+    g_val = reinterpret_cast<const float*>(g_col) + nnz;
+  }
+  // plain-struct view of the arguments (all loads below are from __restrict__
+  // const pointers, so row pointers / chunk rows come in through the scalar cache)
+  const struct {
+    const int* __restrict__ rowptr; const int* __restrict__ col; const float* __restrict__ val;
+    const float* __restrict__ B; float* __restrict__ C; float* __restrict__ P;
+    const int* __restrict__ chunk_row; const float* __restrict__ bias;
+    int relu, nchunks, T, m, nnz, k;
+  } a = {g_rowptr, g_col, g_val, g_B, g_C, g_P, g_chunk_row, g_bias, relu, nchunks, T, m, nnz, kk};
+  const int lane = threadIdx.x & 63;
+  const int wib  = sgpr(threadIdx.x >> 6);
+
+  // XCD-aware chunk ranges: blocks b and b+8 share an XCD (round-robin dispatch),
+  // so XCD x walks the contiguous chunk range [x*N/8, (x+1)*N/8) — neighbouring
+  // rows (which share neighbours after RCM/Gorder) meet in one 4 MiB L2.
+  // Placement only affects speed, never the result.
+  const int xcd           = blockIdx.x & 7;
+  const int wave_in_xcd   = (blockIdx.x >> 3) * 4 + wib;
+  const int waves_per_xcd = (gridDim.x >> 3) * 4;
+  const int c_lo = (int)(((long long)a.nchunks * xcd) >> 3);
+  const int c_hi = (int)(((long long)a.nchunks * (xcd + 1)) >> 3);
+
+  const int  fcol   = blockIdx.y * (64 * VEC) + lane * VEC;   // first feature column of this lane
+  const bool active = fcol < a.k;
+  const float* __restrict__ Bl = a.B + (active ? fcol : 0);
+  const size_t k = (size_t)a.k;
+
+  float bias[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) bias[i] = 0.f;
+  if (EPI) {
+    if (active && a.bias) load_vec<VEC>(a.bias + fcol, bias);
+  }
+
+  for (int c = c_lo + wave_in_xcd; c < c_hi; c += waves_per_xcd) {
+    const int start = c * a.T;
+    const int end   = (int)min((long long)start + a.T, (long long)a.nnz);
+    int r = a.chunk_row[c];
+    int row_end    = a.rowptr[r + 1];
+    int row_end_nx = (r + 1 < a.m) ? a.rowptr[r + 2] : -1;
+    bool head = a.rowptr[r] < start;      // row r began in an earlier chunk
+    int pos = start;
+    int last_flush = start;
+
+    float acc[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+
+    // row r is finished at `pos`: write it out and step to the next row
+    auto flush = [&]() {
+      if (head) {
+        if (active) store_vec<VEC>(a.P + (size_t)(2 * c) * k + fcol, acc);
+      } else {
+        if (EPI) {
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) {
+            acc[i] += bias[i];
+            if (a.relu) acc[i] = fmaxf(acc[i], 0.f);
+          }
+        }
+        if (active) store_vec<VEC>(a.C + (size_t)r * k + fcol, acc);
+      }
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+      head = false;
+      last_flush = pos;
+      ++r;
+      row_end    = row_end_nx;
+      row_end_nx = (r + 1 < a.m) ? a.rowptr[r + 2] : -1;
+    };
+
+    while (pos == row_end) flush();        // leading empty rows (chunk 0 only)
+
+    for (int base = start; base < end; base += 64) {
+      const int cnt = min(64, end - base);
+      int   cj = 0;
+      float vj = 0.f;
+      if (lane < cnt) { cj = a.col[base + lane]; vj = a.val[base + lane]; }
+
+      int j = 0;
+      for (; j + U <= cnt; j += U) {
+        float b[U][VEC];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int cu = __builtin_amdgcn_readlane(cj, j + u);
+          load_vec<VEC>(Bl + (size_t)cu * k, b[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const float vu = __builtin_bit_cast(float,
+              __builtin_amdgcn_readlane(__builtin_bit_cast(int, vj), j + u));
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) acc[i] = fmaf(vu, b[u][i], acc[i]);
+          ++pos;
+          while (pos == row_end) flush();
+        }
+      }
+      for (; j < cnt; ++j) {               // ragged tail (last chunk of the matrix only)
+        float b1[VEC];
+        const int cu = __builtin_amdgcn_readlane(cj, j);
+        const float vu = __builtin_bit_cast(float,
+            __builtin_amdgcn_readlane(__builtin_bit_cast(int, vj), j));
+        load_vec<VEC>(Bl + (size_t)cu * k, b1);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i] = fmaf(vu, b1[i], acc[i]);
+        ++pos;
+        while (pos == row_end) flush();
+      }
+    }
+
+    // the row piece that sticks out of the chunk's end
+    if (last_flush != end) {
+      const int slot = head ? 2 * c : 2 * c + 1;
+      if (active) store_vec<VEC>(a.P + (size_t)slot * k + fcol, acc);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// fix-up: one wave per chunk boundary c (1..nchunks-1).  The boundary that is the
+// FIRST one inside a row owns that row: C[r] = P[2*c0+1] + P[2*(c0+1)] + ... +
+// P[2*c1] in chunk order (c0 = chunk holding the row's first non-zero).
+// ---------------------------------------------------------------------------
+template <bool EPI>
+__global__ void __launch_bounds__(256)
+spmm_fixup_kernel(const int* __restrict__ g_rowptr, const float* __restrict__ g_P,
+                  float* __restrict__ g_C, const int* __restrict__ g_chunk_row,
+                  const float* __restrict__ g_bias, const int* __restrict__ g_nnz_dev,
+                  int relu, int nchunks, int T, int kk) {
+  if (g_nnz_dev) nchunks = (int)(((long long)(*g_nnz_dev) + T - 1) / T);
+  const struct {
+    const int* __restrict__ rowptr; const float* __restrict__ P; float* __restrict__ C;
+    const int* __restrict__ chunk_row; const float* __restrict__ bias; int relu, nchunks, T, k;
+  } a = {g_rowptr, g_P, g_C, g_chunk_row, g_bias, relu, nchunks, T, kk};
+  const int lane = threadIdx.x & 63;
+  const int c = sgpr(blockIdx.x * 4 + (threadIdx.x >> 6)) + 1;
+  if (c >= a.nchunks) return;
+  const int r  = a.chunk_row[c];
+  const int rs = a.rowptr[r];
+  const long long start = (long long)c * a.T;
+  if (!(rs < start && rs / a.T == c - 1)) return;
+  const int re = a.rowptr[r + 1];
+  const int c1 = (re - 1) / a.T;
+  const size_t k = (size_t)a.k;
+  for (int x = lane; x < a.k; x += 64) {
+    float s = a.P[(size_t)(2 * (c - 1) + 1) * k + x];
+    for (int cc = c; cc <= c1; ++cc) s += a.P[(size_t)(2 * cc) * k + x];
+    if (EPI) {
+      if (a.bias) s += a.bias[x];
+      if (a.relu) s = fmaxf(s, 0.f);
+    }
+    a.C[(size_t)r * k + x] = s;
+  }
+}
+
+// nnz == 0: C = act(bias) (or zeros)
+__global__ void spmm_empty_kernel(float* C, const float* bias, int relu, long long total, int k) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (; i < total; i += stride) {
+    float s = bias ? bias[i % k] : 0.f;
+    if (relu) s = fmaxf(s, 0.f);
+    C[i] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// row gather  dst[r,:] = src[idx[r],:]   (permutate.cu:3-21 counterpart)
+// one wave per row, float4 when k%4==0, grid-stride over rows.
+// ---------------------------------------------------------------------------
+template <int VEC>
+__global__ void __launch_bounds__(256)
+gather_rows_kernel(float* __restrict__ dst, const float* __restrict__ src,
+                   const int* __restrict__ idx, int nrows, int k) {
+  const int lane = threadIdx.x & 63;
+  const int wave = sgpr(blockIdx.x * 4 + (threadIdx.x >> 6));
+  const int nwaves = gridDim.x * 4;
+  for (int r = wave; r < nrows; r += nwaves) {
+    const int s = idx[r];
+    const float* sp = src + (size_t)s * k;
+    float* dp = dst + (size_t)r * k;
+    for (int x = lane * VEC; x < k; x += 64 * VEC) {
+      float t[VEC];
+      load_vec<VEC>(sp + x, t);
+      store_vec<VEC>(dp + x, t);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// host-side launchers
+// ---------------------------------------------------------------------------
+hipError_t launch_plan_chunk_rows(const int* rowptr, int m, int T, int nchunks,
+                                  int* chunk_row, hipStream_t s) {
+  if (nchunks <= 0) return hipSuccess;
+  const int bs = 256;
+  plan_chunk_rows_kernel<<<(nchunks + bs - 1) / bs, bs, 0, s>>>(rowptr, m, T, nchunks, chunk_row);
+  return hipGetLastError();
+}
+
+template <int VEC, int U>
+static hipError_t launch_main(const SpmmArgs& a, int nblocks, bool epi, hipStream_t s) {
+  const int tiles = (a.k + 64 * VEC - 1) / (64 * VEC);
+  dim3 grid(nblocks, tiles), block(256);
+#define GCN_MAIN_ARGS a.rowptr, a.col, a.val, a.B, a.C, a.P, a.chunk_row, a.bias, a.nnz_dev, \
+                      a.relu, a.nchunks, a.T, a.m, a.nnz, a.k
+  if (epi) spmm_chunk_kernel<VEC, U, true><<<grid, block, 0, s>>>(GCN_MAIN_ARGS);
+  else     spmm_chunk_kernel<VEC, U, false><<<grid, block, 0, s>>>(GCN_MAIN_ARGS);
+#undef GCN_MAIN_ARGS
+  return hipGetLastError();
+}
+
+int pick_vec(int k, const void* B, const void* C, const void* P) {
+  const uintptr_t al = (uintptr_t)B | (uintptr_t)C | (uintptr_t)P;
+  if (k % 4 == 0 && k > 128 && (al & 15) == 0) return 4;
+  if (k % 2 == 0 && k > 64 && (al & 7) == 0) return 2;
+  return 1;
+}
+
+hipError_t launch_spmm(const SpmmArgs& a, int cu_count, hipStream_t s) {
+  const bool epi = (a.bias != nullptr) || a.relu;
+  if (a.m <= 0 || a.k <= 0) return hipSuccess;
+  const int ng = a.nchunks_grid;          // chunk count the grids are sized for (>= actual)
+  if (ng == 0) {
+    const long long total = (long long)a.m * a.k;
+    int nb = (int)((total + 255) / 256);
+    if (nb > 4096) nb = 4096;
+    spmm_empty_kernel<<<nb, 256, 0, s>>>(a.C, a.bias, a.relu, total, a.k);
+    return hipGetLastError();
+  }
+  // persistent grid: up to 8 blocks of 4 waves per CU, multiple of 8 blocks (XCDs)
+  int nblocks = (ng + 3) / 4;
+  const int cap = cu_count * 8;
+  if (nblocks > cap) nblocks = cap;
+  nblocks = (nblocks + 7) & ~7;
+  hipError_t e;
+  switch (pick_vec(a.k, a.B, a.C, a.P)) {
+    case 4:  e = launch_main<4, 4>(a, nblocks, epi, s); break;
+    case 2:  e = launch_main<2, 8>(a, nblocks, epi, s); break;
+    default: e = launch_main<1, 8>(a, nblocks, epi, s); break;
+  }
+  if (e != hipSuccess) return e;
+  if (ng > 1) {
+    const int nb = (ng - 1 + 3) / 4;
+    if (epi) spmm_fixup_kernel<true><<<nb, 256, 0, s>>>(a.rowptr, a.P, a.C, a.chunk_row, a.bias,
+                                                        a.nnz_dev, a.relu, a.nchunks, a.T, a.k);
+    else     spmm_fixup_kernel<false><<<nb, 256, 0, s>>>(a.rowptr, a.P, a.C, a.chunk_row, a.bias,
+                                                         a.nnz_dev, a.relu, a.nchunks, a.T, a.k);
+    e = hipGetLastError();
+  }
+  return e;
+}
+
+hipError_t launch_gather_rows(float* dst, const float* src, const int* idx, int nrows, int k,
+                              hipStream_t s) {
+  if (nrows <= 0 || k <= 0) return hipSuccess;
+  int nb = (nrows + 3) / 4;
+  if (nb > 8192) nb = 8192;
+  const uintptr_t al = (uintptr_t)dst | (uintptr_t)src;
+  if (k % 4 == 0 && (al & 15) == 0) gather_rows_kernel<4><<<nb, 256, 0, s>>>(dst, src, idx, nrows, k);
+  else                              gather_rows_kernel<1><<<nb, 256, 0, s>>>(dst, src, idx, nrows, k);
+  return hipGetLastError();
+}
+
+}  // namespace gcn

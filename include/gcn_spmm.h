@@ -1,0 +1,161 @@
+/*
+ * gcn_spmm.h — C ABI of libgcnspmm.so, the MI355X (gfx950) GCN aggregation library.
+ *
+ * Everything here is `extern "C"`, plain pointers and sizes; no torch types.
+ * Two groups of entry points:
+ *
+ *  (1) NATIVE API (gcn_*): what the Python host layer (gcn_amd/) binds.  Explicit
+ *      stream, explicit status codes, cached plan object.
+ *  (2) DROP-IN API: the exact symbols / signatures the reference's ctypes call
+ *      sites bind (pygcn/gcn6.py:21-25).  They are exported both from
+ *      libgcnspmm.so and from five tiny shared objects that carry the reference's
+ *      file names (flexspmm.so, cuspmm.so, tile.so, permutate.so, renumber.so),
+ *      so that gcn6.py loads them unchanged.  See INTEGRATION.md.
+ *
+ * Each declaration cites the reference interface it replaces (file:line under
+ * the reference tree guohaoqiang/gcn @ v1).
+ */
+#ifndef GCN_SPMM_H
+#define GCN_SPMM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------- */
+/* status codes (native API).  The reference has no error convention at all   */
+/* (void functions, cuspmm.cu:3-21 only prints) — the drop-in symbols keep    */
+/* `void`, print to stderr and abort() on a HIP failure so it is never silent.*/
+/* ------------------------------------------------------------------------- */
+#define GCN_OK                 0
+#define GCN_ERR_INVALID_ARG    1
+#define GCN_ERR_HIP            2
+#define GCN_ERR_NO_DEVICE      3
+#define GCN_ERR_CAPACITY       4   /* caller buffer too small for the packed plan */
+#define GCN_ERR_ALLOC          5
+
+const char* gcn_status_string(int status);
+/* library version, "major.minor.patch" */
+const char* gcn_version(void);
+/* number of compute units of the current device (replaces the per-call
+ * cudaGetDeviceProperties of flexspmm.cu:506-508 / tile.cu:118-122); <0 on error */
+int gcn_device_cu_count(void);
+
+/* ------------------------------------------------------------------------- */
+/* (1a) SpMM plan + launch:   C[m x k] = A[m x n, CSR fp32] * B[n x k]        */
+/*      replaces  cuspmm()   cuspmm.cu:23-68   (the math: op(A)=A, op(B)=B,   */
+/*                row-major B and C, alpha=1, beta=0)                         */
+/*      and       flexspmm() flexspmm.cu:499-544 (the launcher + 5 kernels)   */
+/* ------------------------------------------------------------------------- */
+typedef struct gcn_spmm_plan gcn_spmm_plan_t;
+
+/* Build the per-graph schedule (equal-nnz chunks + first row of each chunk) on
+ * the device.  `rowptr_dev` is the int32 CSR row pointer [m+1] in device memory;
+ * it is only read during this call.  `chunk_nnz` = 0 picks a size automatically
+ * (multiple of 64).  The plan owns a small device buffer and a grow-only
+ * workspace for the partial sums of rows that straddle chunk boundaries. */
+int gcn_spmm_plan_create(gcn_spmm_plan_t** plan, const int32_t* rowptr_dev,
+                         int32_t m, int32_t n, int32_t nnz, int32_t chunk_nnz,
+                         void* stream);
+int gcn_spmm_plan_destroy(gcn_spmm_plan_t* plan);
+/* introspection (tests, bench) */
+int32_t gcn_spmm_plan_num_chunks(const gcn_spmm_plan_t* plan);
+int32_t gcn_spmm_plan_chunk_nnz(const gcn_spmm_plan_t* plan);
+/* bytes of workspace the plan needs for feature width k */
+size_t  gcn_spmm_plan_workspace_bytes(const gcn_spmm_plan_t* plan, int32_t k);
+
+/* C = A*B.  All pointers are device pointers; C is fully overwritten (no need
+ * to pre-zero, unlike gcn6.py:37).  Asynchronous on `stream` (NULL = the legacy
+ * default stream, which is what the reference launches on, flexspmm.cu:512).
+ * Deterministic: no atomics, each row is summed in CSR order within a chunk
+ * and chunk partials are added in chunk order. */
+int gcn_spmm_csr_f32(gcn_spmm_plan_t* plan,
+                     const int32_t* rowptr_dev, const int32_t* col_dev,
+                     const float* val_dev, const float* B_dev, float* C_dev,
+                     int32_t k, void* stream);
+
+/* Same, plus a fused epilogue  C = act(A*B + bias)  (bias may be NULL;
+ * relu = 0/1).  Covers gcn6.py:141-142,245 (bias add, ReLU) — SURVEY §8(f).1 */
+int gcn_spmm_csr_f32_bias_relu(gcn_spmm_plan_t* plan,
+                     const int32_t* rowptr_dev, const int32_t* col_dev,
+                     const float* val_dev, const float* B_dev, float* C_dev,
+                     const float* bias_dev, int32_t relu,
+                     int32_t k, void* stream);
+
+/* One-shot convenience with an internal plan cache keyed on (rowptr_dev, m, nnz);
+ * this is the body of the drop-in `cuspmm` symbol. */
+int gcn_spmm_csr_f32_oneshot(const int32_t* rowptr_dev, const int32_t* col_dev,
+                     const float* val_dev, const float* B_dev, float* C_dev,
+                     int32_t m, int32_t n, int32_t nnz, int32_t k, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* (1b) feature-row permutation  dst[r,:] = src[idx[r],:]                     */
+/*      replaces flexspmm_v9_permuteX / put_back / permutate()                */
+/*      permutate.cu:3-59                                                     */
+/* ------------------------------------------------------------------------- */
+int gcn_gather_rows_f32(float* dst_dev, const float* src_dev, const int32_t* idx_dev,
+                        int32_t nrows, int32_t k, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* (1c) host-side reorderers (CPU, bit-exact with the reference's integer      */
+/*      vectors).  rank_out[old] = new, n entries, computed from a CSR graph   */
+/*      (one directed edge per stored entry, self-loops included —            */
+/*      edgelist.cuh:16-25).                                                  */
+/*      order_deg   order_deg.cu:19-45    which: 0 total(in+out) 1 out 2 in   */
+/*      order_rcm   order_rcm.cu:15-33 + algo_bfs.cu:11-39                    */
+/*      gorder      order_gorder.cu:13-143 + unitheap.cu (RCM∘Gorder)         */
+/* ------------------------------------------------------------------------- */
+int gcn_order_deg(const int32_t* rowptr, const int32_t* col, int32_t n, int32_t nnz,
+                  int32_t which, int32_t desc, int64_t* rank_out);
+int gcn_order_rcm(const int32_t* rowptr, const int32_t* col, int32_t n, int32_t nnz,
+                  int32_t directed, int64_t* rank_out);
+int gcn_order_gorder(const int32_t* rowptr, const int32_t* col, int32_t n, int32_t nnz,
+                     int32_t window, int64_t* rank_out);
+/* CSR rewrite under a rank: rows/cols relabelled, each row's columns sorted
+ * ascending with values carried along (renumber.cu:190-217); vomp_out[new]=old. */
+int gcn_csr_apply_rank(int32_t* rowptr, int32_t* col, float* vals, int32_t n, int32_t nnz,
+                       const int64_t* rank, int32_t* vomp_out);
+
+/* ------------------------------------------------------------------------- */
+/* (2) DROP-IN symbols — identical names and argument lists to the reference.  */
+/* ------------------------------------------------------------------------- */
+
+/* renumber.so — renumber.cu:23 (dfs), :157 (gorder), :233 (perm_apply), :319 (rabbit).
+ * All pointers HOST, CSR rewritten in place, vomp[new] = old. */
+void dfs(int* rowPtr, int* col, float* vals, int* vomp, int m, int n, int nnz);
+void gorder(int* rowPtr, int* col, float* vals, int* vomp, int m, int n, int nnz);
+void perm_apply(int* rowPtr, int* col, float* vals, int* vomp, int m, int n, int nnz);
+void rabbit(int* rowPtr, int* col, float* vals, int* vomp, int m, int n, int nnz);
+
+/* tile.so — tile.cu:104-106.  All pointers HOST.  Packs THIS library's plan
+ * (not the reference's defective tile-seg arrays, SURVEY defects D1-D3) into the
+ * caller's buffers; capacities honoured: seg_rowPtr nnz ints, segNzCV 2*nnz
+ * floats, segVoMap nnz ints, grouped_tailSeg/next_seg 256 ints (gcn6.py:334-339).
+ * Encoding documented in INTEGRATION.md. */
+void csr2tile(int* rowPtr, int* colIdx, float* vals, int m, int n, int nnz,
+              int* vo_mp, int* segVoMap, int* seg_rowPtr, float* segNzCV,
+              int* grouped_tailSeg, int* next_seg, int tm, int* n_segs);
+
+/* flexspmm.so — flexspmm.cu:499-502.  All pointers DEVICE.  Consumes the arrays
+ * written by this library's csr2tile.  Legacy default stream. */
+void flexspmm(int* seg_rowPtr, float* segNzCV, int* segVoMap,
+              int* grouped_tailSeg, int* next_seg,
+              int m, int n, int k, int n_segs, float* B, float* C);
+
+/* permutate.so — permutate.cu:40-41.  Device pointers; B permuted in place
+ * (B[r,:] <- B[voMp[r],:]); labels untouched exactly like the reference
+ * (`if (false && lane_id==0)`, permutate.cu:17,35). */
+void permutate(float* B, int* voMp, int* labels, int m, int n, int k);
+
+/* cuspmm.so — cuspmm.cu:23-24 (first parameter is declared float* there although
+ * it carries the int32 row pointer; kept for signature parity). */
+void cuspmm(float* rowPtr, int* col, float* vals, float* X, float* C,
+            int m, int n, int nnz, int dim);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GCN_SPMM_H */
