@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""bench.py — the BASELINE.json metric: SpMM GFLOP/s (+ achieved GB/s against the HBM
+roofline) on the Reddit-shaped graph (n = 232 965, nnz ≈ 114.85 M incl. self-loops),
+feature width 128, fp32, no reorder, on 1/2/4/8 MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one aggregation layer over the whole graph: C = Â·H (N = 1), or, for N > 1,
+every rank's row-block SpMM followed by the RCCL all-gather of the layer output (the next
+layer's input) — strong scaling, the graph is fixed.  Inputs are resident in HBM when the
+timed region starts.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import gcn_amd                      # noqa: E402
+from gcn_amd import graphgen        # noqa: E402
+from gcn_amd.dist import RowShardedAdjacency   # noqa: E402
+
+HBM_PEAK = 8.0e12          # B/s, MI355X spec (MI355X_MICROARCH.md); measured copy peak 6.29e12
+K_FEAT = 128
+
+
+def algorithmic_bytes(m, nnz, k):
+    # one gathered feature row + col + val per non-zero, rowptr, C store
+    return nnz * (4 + 4 + 4 * k) + (m + 1) * 4 + m * k * 4
+
+
+def cpu_baseline(rowptr, col, val, n, k, seed):
+    """pygcn's CPU path: torch.spmm(adj_sparse_coo_fp32, dense) exactly as gcn1.py:53 issues it,
+    on this box's host cores (baseline only; bounded to ~30 s)."""
+    rp = rowptr.cpu().long()
+    rows = torch.repeat_interleave(torch.arange(n, dtype=torch.int64), rp[1:] - rp[:-1])
+    idx = torch.stack([rows, col.cpu().long()])
+    adj = torch.sparse_coo_tensor(idx, val.cpu(), (n, n))      # as utils.py:243-250 builds it
+    B = graphgen.random_features(n, k, seed=seed, device="cpu")
+    nnz = int(val.numel())
+    times = []
+    t_begin = time.perf_counter()
+    torch.spmm(adj, B)                                         # warm-up
+    for _ in range(3):
+        t0 = time.perf_counter()
+        torch.spmm(adj, B)
+        times.append(time.perf_counter() - t0)
+        if time.perf_counter() - t_begin > 30:
+            break
+    times.sort()
+    med = times[len(times) // 2]
+    return {
+        "value": round(2.0 * nnz * k / med / 1e9, 3), "unit": "GFLOP/s",
+        "cores": torch.get_num_threads(), "kind": "reference",
+        "sample": f"torch.spmm(sparse_coo fp32, dense) as pygcn/gcn1.py:53, full Reddit-shaped graph "
+                  f"(nnz={nnz}, k={k}), median of {len(times)} runs after 1 warm-up, "
+                  f"os.cpu_count()={os.cpu_count()}, torch {torch.__version__}",
+        "seconds_per_spmm": round(med, 4),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--graph", default="reddit")
+    ap.add_argument("--k", type=int, default=K_FEAT)
+    ap.add_argument("--scale", type=float, default=1.0, help="shrink the graph (debug only; invalidates the metric)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch N>1 with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a HIP device (no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)          # nccl == RCCL on ROCm
+
+    # ---- inputs (same seeds on every rank → identical graph everywhere) -------------------
+    rowptr, col, val, n = graphgen.make_graph(args.graph, device=dev, seed=1, scale=args.scale)
+    nnz, k = int(col.numel()), args.k
+    H = graphgen.random_features(n, k, seed=2, device=dev)
+
+    if world == 1:
+        adj = gcn_amd.CsrAdjacency(rowptr, col, val, (n, n), symmetric=True)
+        out = torch.empty((n, k), dtype=torch.float32, device=dev)
+
+        def step():
+            adj.matmul_raw(H, out=out)
+        local_adj, local_nnz, local_m = adj, nnz, n
+    else:
+        shard = RowShardedAdjacency(rowptr, col, val, n, rank, world,
+                                    lambda rp, ci, va, shape: gcn_amd.CsrAdjacency(rp, ci, va, shape))
+        bufs = [shard.to_padded(H), shard.new_buffer(k, dev)]
+        state = {"i": 0}
+
+        def step():                       # layer l+1 consumes the all-gathered output of layer l
+            src, dst = bufs[state["i"] & 1], bufs[(state["i"] + 1) & 1]
+            shard.layer(src, dst)
+            state["i"] += 1
+        local_adj, local_nnz, local_m = shard.local, shard.local_nnz, shard.rows
+        del rowptr, col, val
+        torch.cuda.empty_cache()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    local_adj.profile_begin(args.steps)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = local_adj.profile_end()
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- roofline of the dominant kernel (spmm_chunk_kernel), this rank's launches ---------
+    kavg = sum(kernel_ms) / max(len(kernel_ms), 1) * 1e-3
+    balg = algorithmic_bytes(local_m, local_nnz, k)
+    achieved = balg / kavg if kavg > 0 else 0.0
+
+    if rank == 0:
+        flops = 2.0 * nnz * k
+        line = {
+            "metric": "SpMM GFLOP/s + achieved HBM GB/s, Reddit feat=128, 1/2/4/8 MI355X",
+            "value": round(flops * args.steps / elapsed / 1e9, 2),
+            "unit": "GFLOP/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.graph}-shaped R-MAT graph, n={n}, nnz={nnz} (incl. self-loops), "
+                            f"feat={k}, fp32, no reorder; step = C = Â·H"
+                            + ("" if world == 1 else " per row block + RCCL all-gather of the layer output"),
+                "n": n, "nnz": nnz, "k": k,
+                "parallelism": "single GPU" if world == 1 else f"1-D row partition x{world} (nnz-balanced), all-gather per layer",
+                "chunks": f"{local_adj.num_chunks} x {local_adj.chunk_size} nnz",
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": "spmm_chunk_kernel<VEC=2,U=8>" if k == 128 else "spmm_chunk_kernel",
+                "achieved": round(achieved / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK, 4),
+                "frac_of_measured_copy_peak_6.29TBps": round(achieved / 6.29e12, 4),
+                "algorithmic_bytes_per_launch": balg,
+                "kernel_ms_avg": round(kavg * 1e3, 4), "kernel_ms_min": round(min(kernel_ms), 4) if kernel_ms else None,
+                "kernel_launches_timed": len(kernel_ms),
+                "traffic": None,
+            },
+            "gflops_kernel_only": round(2.0 * local_nnz * k / kavg / 1e9, 1) if kavg > 0 else None,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(rowptr, col, val, n, k, seed=2)
+        print(json.dumps(line), flush=True)
+
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,86 @@
+"""ctypes binding of libgcnspmm.so (the C ABI declared in include/gcn_spmm.h).
+
+The product path has NO CPU fallback: if the library is missing or a call returns a
+non-zero status, a GcnAmdError is raised.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libgcnspmm.so")
+DROPIN_DIR = os.path.join(_HERE, "dropin")
+
+
+class GcnAmdError(RuntimeError):
+    pass
+
+
+_c_i32 = ctypes.c_int32
+_c_p = ctypes.c_void_p
+
+# name -> (restype, argtypes)  — one entry per symbol declared in include/gcn_spmm.h
+SIGNATURES = {
+    "gcn_status_string": (ctypes.c_char_p, [ctypes.c_int]),
+    "gcn_version": (ctypes.c_char_p, []),
+    "gcn_device_cu_count": (ctypes.c_int, []),
+    "gcn_spmm_plan_create": (ctypes.c_int, [ctypes.POINTER(_c_p), _c_p, _c_i32, _c_i32, _c_i32, _c_i32, _c_p]),
+    "gcn_spmm_plan_destroy": (ctypes.c_int, [_c_p]),
+    "gcn_spmm_plan_num_chunks": (_c_i32, [_c_p]),
+    "gcn_spmm_plan_chunk_nnz": (_c_i32, [_c_p]),
+    "gcn_spmm_plan_workspace_bytes": (ctypes.c_size_t, [_c_p, _c_i32]),
+    "gcn_spmm_csr_f32": (ctypes.c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i32, _c_p]),
+    "gcn_spmm_csr_f32_bias_relu": (ctypes.c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i32, _c_i32, _c_p]),
+    "gcn_spmm_profile_begin": (ctypes.c_int, [_c_p, _c_i32]),
+    "gcn_spmm_profile_end": (ctypes.c_int, [_c_p, _c_p, _c_p]),
+    "gcn_spmm_csr_f32_oneshot": (ctypes.c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_i32, _c_i32, _c_i32, _c_i32, _c_p]),
+    "gcn_gather_rows_f32": (ctypes.c_int, [_c_p, _c_p, _c_p, _c_i32, _c_i32, _c_p]),
+    "gcn_order_deg": (ctypes.c_int, [_c_p, _c_p, _c_i32, _c_i32, _c_i32, _c_i32, _c_p]),
+    "gcn_order_rcm": (ctypes.c_int, [_c_p, _c_p, _c_i32, _c_i32, _c_i32, _c_p]),
+    "gcn_order_gorder": (ctypes.c_int, [_c_p, _c_p, _c_i32, _c_i32, _c_i32, _c_p]),
+    "gcn_csr_apply_rank": (ctypes.c_int, [_c_p, _c_p, _c_p, _c_i32, _c_i32, _c_p, _c_p]),
+    # drop-in symbols (reference signatures; void)
+    "dfs": (None, [_c_p, _c_p, _c_p, _c_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "gorder": (None, [_c_p, _c_p, _c_p, _c_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "perm_apply": (None, [_c_p, _c_p, _c_p, _c_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "rabbit": (None, [_c_p, _c_p, _c_p, _c_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "csr2tile": (None, [_c_p, _c_p, _c_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_p, _c_p, _c_p,
+                        _c_p, _c_p, _c_p, ctypes.c_int, _c_p]),
+    "flexspmm": (None, [_c_p, _c_p, _c_p, _c_p, _c_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                        ctypes.c_int, _c_p, _c_p]),
+    "permutate": (None, [_c_p, _c_p, _c_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "cuspmm": (None, [_c_p, _c_p, _c_p, _c_p, _c_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+}
+
+_lib = None
+
+
+def load(path=None):
+    """Load (once) and return the ctypes handle; raises GcnAmdError if absent."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise GcnAmdError(
+            f"{p} not found: the HIP library is not built. Run `python -m gcn_amd.build` "
+            "(there is no CPU fallback for the SpMM path).")
+    try:
+        lib = ctypes.CDLL(p)
+    except OSError as e:  # pragma: no cover - environment dependent
+        raise GcnAmdError(f"cannot load {p}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise GcnAmdError(f"{p} does not export `{name}` declared in include/gcn_spmm.h") from e
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = load().gcn_status_string(status).decode()
+        raise GcnAmdError(f"{what}: {msg} (status {status})")

@@ -23,6 +23,9 @@ struct gcn_spmm_plan {
   size_t ws_bytes;
   int cu_count;
   int device;
+  // live kernel timing (gcn_spmm_profile_begin/_end)
+  std::vector<hipEvent_t> ev;   // 2 per recorded launch
+  int prof_cap, prof_n;
 };
 
 namespace {
@@ -105,6 +108,7 @@ int gcn_spmm_plan_create(gcn_spmm_plan_t** out, const int32_t* rowptr_dev, int32
   p->T = chunk_nnz ? chunk_nnz : auto_chunk_nnz(nnz, cu);
   p->nchunks = (int)(((long long)nnz + p->T - 1) / p->T);
   p->chunk_row = nullptr; p->ws = nullptr; p->ws_bytes = 0; p->cu_count = cu;
+  p->prof_cap = p->prof_n = 0;
   (void)hipGetDevice(&p->device);
   if (p->nchunks > 0) {
     if (hipMalloc((void**)&p->chunk_row, sizeof(int) * (size_t)p->nchunks) != hipSuccess) {
@@ -123,6 +127,7 @@ int gcn_spmm_plan_destroy(gcn_spmm_plan_t* p) {
   if (!p) return GCN_OK;
   if (p->chunk_row) (void)hipFree(p->chunk_row);
   if (p->ws) (void)hipFree(p->ws);
+  for (auto& e : p->ev) (void)hipEventDestroy(e);
   delete p;
   return GCN_OK;
 }
@@ -150,7 +155,38 @@ int gcn_spmm_csr_f32_bias_relu(gcn_spmm_plan_t* p, const int32_t* rowptr, const 
   a.chunk_row = p->chunk_row; a.bias = bias; a.relu = relu ? 1 : 0;
   a.nchunks = p->nchunks; a.T = p->T; a.m = p->m; a.nnz = p->nnz; a.k = k;
   a.nnz_dev = nullptr; a.nchunks_grid = p->nchunks;
+  if (p->prof_cap > 0 && p->prof_n < p->prof_cap) {
+    a.ev_start = p->ev[2 * p->prof_n];
+    a.ev_stop = p->ev[2 * p->prof_n + 1];
+    ++p->prof_n;
+  }
   return gcn::launch_spmm(a, p->cu_count, (hipStream_t)stream) == hipSuccess ? GCN_OK : GCN_ERR_HIP;
+}
+
+int gcn_spmm_profile_begin(gcn_spmm_plan_t* p, int32_t capacity) {
+  if (!p || capacity <= 0 || p->prof_cap > 0) return GCN_ERR_INVALID_ARG;
+  p->ev.resize(2 * (size_t)capacity);
+  for (auto& e : p->ev)
+    if (hipEventCreate(&e) != hipSuccess) return GCN_ERR_HIP;
+  p->prof_cap = capacity;
+  p->prof_n = 0;
+  return GCN_OK;
+}
+
+int gcn_spmm_profile_end(gcn_spmm_plan_t* p, float* ms_out, int32_t* count_out) {
+  if (!p || !count_out || p->prof_cap <= 0) return GCN_ERR_INVALID_ARG;
+  int st = GCN_OK;
+  for (int i = 0; i < p->prof_n; ++i) {
+    float ms = 0.f;
+    if (hipEventSynchronize(p->ev[2 * i + 1]) != hipSuccess ||
+        hipEventElapsedTime(&ms, p->ev[2 * i], p->ev[2 * i + 1]) != hipSuccess) st = GCN_ERR_HIP;
+    if (ms_out) ms_out[i] = ms;
+  }
+  *count_out = p->prof_n;
+  for (auto& e : p->ev) (void)hipEventDestroy(e);
+  p->ev.clear();
+  p->prof_cap = p->prof_n = 0;
+  return st;
 }
 
 int gcn_spmm_csr_f32(gcn_spmm_plan_t* p, const int32_t* rowptr, const int32_t* col,
@@ -164,7 +200,7 @@ int gcn_spmm_csr_f32(gcn_spmm_plan_t* p, const int32_t* rowptr, const int32_t* c
 int gcn_spmm_csr_f32_oneshot(const int32_t* rowptr, const int32_t* col, const float* val,
                              const float* B, float* C, int32_t m, int32_t n, int32_t nnz,
                              int32_t k, void* stream) {
-  static gcn_spmm_plan scratch = {};
+  static gcn_spmm_plan scratch{};
   static size_t chunk_cap = 0;
   if (m < 0 || n < 0 || nnz < 0 || k < 0) return GCN_ERR_INVALID_ARG;
   const int cu = cu_count_cached();
@@ -373,7 +409,7 @@ void csr2tile(int* rowPtr, int* colIdx, float* vals, int m, int n, int nnz, int*
 void flexspmm(int* seg_rowPtr, float* segNzCV, int* segVoMap, int* grouped_tailSeg, int* next_seg,
               int m, int n, int k, int n_segs, float* B, float* C) {
   (void)grouped_tailSeg; (void)next_seg; (void)n;
-  static gcn_spmm_plan scratch = {};
+  static gcn_spmm_plan scratch{};
   if (m <= 0 || k <= 0) return;
   const int cu = cu_count_cached();
   if (cu <= 0) { std::fprintf(stderr, "libgcnspmm: flexspmm: no HIP device\n"); std::abort(); }

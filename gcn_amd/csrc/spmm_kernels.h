@@ -22,6 +22,9 @@ struct SpmmArgs {
   // and the host sizes its grids with the upper bound nchunks_grid.
   const int* nnz_dev;
   int nchunks_grid;
+  // optional HIP events recorded on the launch stream right before / after the MAIN
+  // kernel (not the fix-up) — the live kernel timing bench.py reports (null = off)
+  hipEvent_t ev_start = nullptr, ev_stop = nullptr;
 };
 
 hipError_t launch_plan_chunk_rows(const int* rowptr, int m, int T, int nchunks,

@@ -328,12 +328,14 @@ hipError_t launch_spmm(const SpmmArgs& a, int cu_count, hipStream_t s) {
   if (nblocks > cap) nblocks = cap;
   nblocks = (nblocks + 7) & ~7;
   hipError_t e;
+  if (a.ev_start && (e = hipEventRecord(a.ev_start, s)) != hipSuccess) return e;
   switch (pick_vec(a.k, a.B, a.C, a.P)) {
     case 4:  e = launch_main<4, 4>(a, nblocks, epi, s); break;
     case 2:  e = launch_main<2, 8>(a, nblocks, epi, s); break;
     default: e = launch_main<1, 8>(a, nblocks, epi, s); break;
   }
   if (e != hipSuccess) return e;
+  if (a.ev_stop && (e = hipEventRecord(a.ev_stop, s)) != hipSuccess) return e;
   if (ng > 1) {
     const int nb = (ng - 1 + 3) / 4;
     if (epi) spmm_fixup_kernel<true><<<nb, 256, 0, s>>>(a.rowptr, a.P, a.C, a.chunk_row, a.bias,

@@ -1,0 +1,95 @@
+"""1-D row partition of Â across the GPUs of one node + all-gather of layer outputs.
+
+The reference is single-GPU (device 0 hard-coded, flexspmm.cu:507); this module is the
+MI355X-native extension BASELINE.json asks for: rank p owns a contiguous,
+nnz-balanced row block Â[rows_p, :], computes H'_p = Â[rows_p, :] · H with the same HIP
+kernel, and the next layer's input H' is assembled with ONE RCCL all-gather over xGMI.
+
+Zero-copy layout: shards have unequal row counts, so every shard is padded to
+`max_rows` and the gathered buffer is [world * max_rows, k].  Instead of compacting
+that buffer after every layer, the column indices of the local block are remapped ONCE
+to the padded numbering (col' = owner(col) * max_rows + local_index(col)); the local
+SpMM writes straight into this rank's slot of the buffer and the all-gather is done
+in place.  Summation order inside a row is unchanged by the partition, so every row
+equals the single-GPU result bit for bit.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def partition_rows(rowptr, world, balance="nnz"):
+    """Row boundaries [world+1] of contiguous blocks with (nearly) equal nnz (or rows)."""
+    rowptr = np.asarray(rowptr, dtype=np.int64)
+    m = len(rowptr) - 1
+    if balance == "rows":
+        return np.array([(m * p) // world for p in range(world + 1)], dtype=np.int64)
+    nnz = int(rowptr[-1])
+    targets = np.array([(nnz * p) // world for p in range(1, world)], dtype=np.int64)
+    cuts = np.searchsorted(rowptr, targets, side="left")
+    bounds = np.concatenate([[0], cuts, [m]]).astype(np.int64)
+    return np.maximum.accumulate(np.minimum(bounds, m))
+
+
+class RowShardedAdjacency:
+    """This rank's row block of Â in the padded-gather numbering.
+
+    make_local(rowptr_i32, col_i32, val_f32, shape) must return an object with
+    ``matmul_raw(dense, out=...)`` — gcn_amd.CsrAdjacency on the GPU; the gloo/CPU tests
+    inject an oracle-backed stand-in (the product path has no CPU compute).
+    """
+
+    def __init__(self, rowptr, col, val, n, rank, world, make_local, balance="nnz"):
+        rowptr_h = rowptr.detach().cpu().numpy().astype(np.int64)
+        self.n, self.rank, self.world = int(n), int(rank), int(world)
+        self.bounds = partition_rows(rowptr_h, world, balance)
+        sizes = np.diff(self.bounds)
+        self.max_rows = int(sizes.max())
+        self.row_lo, self.row_hi = int(self.bounds[rank]), int(self.bounds[rank + 1])
+        self.rows = self.row_hi - self.row_lo
+        device = col.device
+        e_lo, e_hi = int(rowptr_h[self.row_lo]), int(rowptr_h[self.row_hi])
+        local_rowptr = torch.from_numpy((rowptr_h[self.row_lo:self.row_hi + 1] - e_lo).astype(np.int32)).to(device)
+        gcol = col[e_lo:e_hi].long()
+        bounds_t = torch.from_numpy(self.bounds).to(device)
+        owner = torch.bucketize(gcol, bounds_t[1:], right=True)
+        pcol = owner * self.max_rows + (gcol - bounds_t[owner])
+        self.local_nnz = e_hi - e_lo
+        self.total_nnz = int(rowptr_h[-1])
+        self.local = make_local(local_rowptr, pcol.to(torch.int32), val[e_lo:e_hi].contiguous(),
+                                (self.rows, self.world * self.max_rows))
+        self._bounds_t = bounds_t
+
+    # global [n, k] -> padded [world*max_rows, k]
+    def to_padded(self, H):
+        out = torch.zeros((self.world * self.max_rows, H.shape[1]), dtype=H.dtype, device=H.device)
+        for p in range(self.world):
+            lo, hi = int(self.bounds[p]), int(self.bounds[p + 1])
+            out[p * self.max_rows: p * self.max_rows + (hi - lo)] = H[lo:hi]
+        return out
+
+    # padded [world*max_rows, k] -> global [n, k]
+    def from_padded(self, Hp):
+        parts = []
+        for p in range(self.world):
+            lo, hi = int(self.bounds[p]), int(self.bounds[p + 1])
+            parts.append(Hp[p * self.max_rows: p * self.max_rows + (hi - lo)])
+        return torch.cat(parts, 0)
+
+    def new_buffer(self, k, device, dtype=torch.float32):
+        return torch.zeros((self.world * self.max_rows, k), dtype=dtype, device=device)
+
+    def layer(self, H_padded, out_padded, group=None):
+        """out = Â · H for the whole graph, in the padded layout, on every rank:
+        local row-block SpMM into this rank's slot, then one in-place all-gather."""
+        k = H_padded.shape[1]
+        slot = out_padded[self.rank * self.max_rows: (self.rank + 1) * self.max_rows]
+        if self.rows:
+            self.local.matmul_raw(H_padded, out=slot[: self.rows])
+        if self.world > 1:
+            try:
+                dist.all_gather_into_tensor(out_padded, slot, group=group)
+            except (RuntimeError, NotImplementedError):     # backends without the flat form
+                views = [out_padded[p * self.max_rows: (p + 1) * self.max_rows] for p in range(self.world)]
+                dist.all_gather(views, slot.clone(), group=group)
+        return out_padded

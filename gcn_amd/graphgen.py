@@ -1,0 +1,116 @@
+"""Deterministic synthetic graphs shaped like the BASELINE configs.
+
+No dataset exists offline, so every config runs on a seeded
+stand-in with the same (n, nnz, degree skew).  The generator is R-MAT with a
+random vertex relabelling (so that "no reorder" really has no locality), de-duplicated,
+symmetrised, self-loops added, and normalised the way the reference does it:
+Â = D^-1/2 (A + I) D^-1/2 computed in fp64 then cast to fp32
+(pygcn/gcnio/util/utils.py:78-90, :243-250).
+
+All tensor work is torch, on whatever device is asked for (the GPU for the
+100 M-nnz cases, the CPU for tests); results are deterministic per device type.
+"""
+import math
+
+import torch
+
+# (n, undirected edges before self-loops, rmat (a,b,c,d))
+# R-MAT skew is picked so that the maximum degree lands near the real dataset's
+# (Reddit: mean 492, max ≈ 21.6 k): with the classic (.57,.19,.19,.05) vertex 0 would
+# be adjacent to every other vertex at this density and de-duplication would remove
+# most samples, which is an easier (cache-friendlier) problem than the real graph.
+SHAPES = {
+    "cora":     dict(n=2485, edges=5069, abcd=(0.25, 0.25, 0.25, 0.25)),
+    "reddit":   dict(n=232965, edges=57307946, abcd=(0.37, 0.25, 0.25, 0.13)),
+    "products": dict(n=2449029, edges=61859140, abcd=(0.45, 0.22, 0.22, 0.11)),
+}
+
+
+def _rmat_pairs(n, count, abcd, gen, device):
+    """`count` (u, v) samples from an R-MAT distribution over a 2^s x 2^s grid, folded to n."""
+    a, b, c, _ = abcd
+    scale = max(1, math.ceil(math.log2(max(n, 2))))
+    u = torch.zeros(count, dtype=torch.int64, device=device)
+    v = torch.zeros(count, dtype=torch.int64, device=device)
+    for _lvl in range(scale):
+        r = torch.rand(count, generator=gen, device=device)
+        # quadrants: [0,a) -> (0,0), [a,a+b) -> (0,1), [a+b,a+b+c) -> (1,0), rest -> (1,1)
+        ubit = (r >= a + b).to(torch.int64)
+        vbit = (((r >= a) & (r < a + b)) | (r >= a + b + c)).to(torch.int64)
+        u = (u << 1) | ubit
+        v = (v << 1) | vbit
+    return u % n, v % n
+
+
+def rmat_undirected_edges(n, edges, abcd=(0.57, 0.19, 0.19, 0.05), seed=0, device="cpu"):
+    """Exactly `edges` distinct undirected edges {u<v} (as one int64 key u*n+v, sorted)."""
+    device = torch.device(device)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    max_edges = n * (n - 1) // 2
+    if edges > max_edges:
+        raise ValueError("more edges requested than the simple graph can hold")
+    keys = torch.empty(0, dtype=torch.int64, device=device)
+    need = edges
+    for _round in range(64):
+        batch = int(need * 1.15) + 1024
+        u, v = _rmat_pairs(n, batch, abcd, gen, device)
+        lo, hi = torch.minimum(u, v), torch.maximum(u, v)
+        ok = lo != hi
+        keys = torch.unique(torch.cat([keys, lo[ok] * n + hi[ok]]))
+        if keys.numel() >= edges:
+            break
+        need = edges - keys.numel()
+    else:  # pragma: no cover
+        raise RuntimeError("R-MAT generator did not reach the requested edge count")
+    if keys.numel() > edges:   # drop a seeded random subset of the surplus
+        perm = torch.randperm(keys.numel(), generator=gen, device=device)[:edges]
+        keys = keys[perm.sort().values]
+    return keys
+
+
+def normalized_adjacency(n, edge_keys, relabel_seed=None):
+    """CSR of Â = D^-1/2 (A+I) D^-1/2 (int32 rowptr/col, fp32 val) from undirected edge keys.
+
+    Returns (rowptr, col, val) on the device of `edge_keys`; columns sorted within rows.
+    """
+    device = edge_keys.device
+    u, v = edge_keys // n, edge_keys % n
+    if relabel_seed is not None:
+        gen = torch.Generator(device=device)
+        gen.manual_seed(relabel_seed)
+        perm = torch.randperm(n, generator=gen, device=device)
+        u, v = perm[u], perm[v]
+    loops = torch.arange(n, dtype=torch.int64, device=device)
+    rows = torch.cat([u, v, loops])
+    cols = torch.cat([v, u, loops])
+    del u, v
+    key = torch.sort(rows * n + cols).values
+    del rows, cols
+    rows, cols = key // n, key % n
+    del key
+    deg = torch.bincount(rows, minlength=n)
+    rowptr = torch.zeros(n + 1, dtype=torch.int64, device=device)
+    rowptr[1:] = torch.cumsum(deg, 0)
+    dinv = deg.to(torch.float64).pow(-0.5)
+    val = (dinv[rows] * dinv[cols]).to(torch.float32)
+    return rowptr.to(torch.int32), cols.to(torch.int32), val
+
+
+def make_graph(name, device="cpu", seed=1, scale=1.0):
+    """(rowptr, col, val, n) of the named BASELINE-shaped graph.  `scale` < 1 shrinks n and
+    the edge count together (same mean degree) for tests."""
+    spec = SHAPES[name]
+    n = max(16, int(spec["n"] * scale))
+    edges = max(n, int(spec["edges"] * scale))
+    edges = min(edges, n * (n - 1) // 2)
+    keys = rmat_undirected_edges(n, edges, spec["abcd"], seed=seed, device=device)
+    rowptr, col, val = normalized_adjacency(n, keys, relabel_seed=seed + 1000)
+    return rowptr, col, val, n
+
+
+def random_features(n, k, seed=2, device="cpu"):
+    """B ~ N(0,1) fp32 [n x k] (the reference standard-scales features, profiling_gcn.py:31-35)."""
+    gen = torch.Generator(device=torch.device(device))
+    gen.manual_seed(seed)
+    return torch.randn((n, k), generator=gen, device=device, dtype=torch.float32)

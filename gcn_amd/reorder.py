@@ -1,0 +1,93 @@
+"""Host-side vertex reorderers (preprocessing), bound from libgcnspmm.so.
+
+numpy in, numpy out.  All integer vectors are bit-exact with the reference
+(order_deg.cu, order_rcm.cu, order_gorder.cu + unitheap.cu, renumber.cu); see
+gcn_amd/csrc/reorder.cpp for the file:line map.  Internal functions return
+``rank[old] = new``; the C-ABI renumber entry points return ``vomp[new] = old``
+and rewrite the CSR in place (renumber.cu:90-95,184-189,520).
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+
+def _p(a):
+    return ctypes.c_void_p(a.ctypes.data)
+
+
+def _csr(rowptr, col):
+    rowptr = np.ascontiguousarray(rowptr, dtype=np.int32)
+    col = np.ascontiguousarray(col, dtype=np.int32)
+    n = rowptr.shape[0] - 1
+    return rowptr, col, n, int(col.shape[0])
+
+
+def order_deg(rowptr, col, which="total", desc=True):
+    """rank[old]=new by degree (total = in+out | out | in), ties by node id (order_deg.cu:8-56)."""
+    rowptr, col, n, nnz = _csr(rowptr, col)
+    out = np.empty(n, dtype=np.int64)
+    w = {"total": 0, "out": 1, "in": 2}[which]
+    _lib.check(_lib.load().gcn_order_deg(_p(rowptr), _p(col), n, nnz, w, int(bool(desc)), _p(out)),
+               "gcn_order_deg")
+    return out
+
+
+def order_rcm(rowptr, col, directed=True):
+    """Reverse Cuthill-McKee rank (order_rcm.cu:15-33)."""
+    rowptr, col, n, nnz = _csr(rowptr, col)
+    out = np.empty(n, dtype=np.int64)
+    _lib.check(_lib.load().gcn_order_rcm(_p(rowptr), _p(col), n, nnz, int(bool(directed)), _p(out)),
+               "gcn_order_rcm")
+    return out
+
+
+def order_gorder(rowptr, col, window=3):
+    """RCM∘Gorder rank (order_gorder.cu:13-31); window 3 is what the C ABI uses (renumber.cu:176)."""
+    rowptr, col, n, nnz = _csr(rowptr, col)
+    out = np.empty(n, dtype=np.int64)
+    _lib.check(_lib.load().gcn_order_gorder(_p(rowptr), _p(col), n, nnz, int(window), _p(out)),
+               "gcn_order_gorder")
+    return out
+
+
+def apply_rank(rowptr, col, vals, rank):
+    """CSR in the new numbering (columns sorted, values carried) and vomp[new]=old."""
+    rowptr, col, n, nnz = _csr(rowptr, col)
+    rowptr, col = rowptr.copy(), col.copy()
+    vals = np.array(vals, dtype=np.float32, copy=True)
+    rank = np.ascontiguousarray(rank, dtype=np.int64)
+    vomp = np.empty(n, dtype=np.int32)
+    _lib.check(_lib.load().gcn_csr_apply_rank(_p(rowptr), _p(col), _p(vals), n, nnz, _p(rank), _p(vomp)),
+               "gcn_csr_apply_rank")
+    return rowptr, col, vals, vomp
+
+
+def _renumber(name, rowptr, col, vals, vomp=None):
+    rowptr, col, n, nnz = _csr(rowptr, col)
+    rowptr, col = rowptr.copy(), col.copy()
+    vals = np.array(vals, dtype=np.float32, copy=True)
+    vomp = np.arange(n, dtype=np.int32) if vomp is None else np.array(vomp, dtype=np.int32, copy=True)
+    getattr(_lib.load(), name)(_p(rowptr), _p(col), _p(vals), _p(vomp), n, n, nnz)
+    return rowptr, col, vals, vomp
+
+
+def dfs(rowptr, col, vals):
+    """renumber.so:dfs (renumber.cu:23-155) → (rowptr, col, vals, vomp)."""
+    return _renumber("dfs", rowptr, col, vals)
+
+
+def gorder(rowptr, col, vals):
+    """renumber.so:gorder (renumber.cu:157-230)."""
+    return _renumber("gorder", rowptr, col, vals)
+
+
+def rabbit(rowptr, col, vals):
+    """renumber.so:rabbit (renumber.cu:319-522)."""
+    return _renumber("rabbit", rowptr, col, vals)
+
+
+def perm_apply(rowptr, col, vals, vomp):
+    """renumber.so:perm_apply (renumber.cu:233-318): apply a given vomp[new]=old."""
+    return _renumber("perm_apply", rowptr, col, vals, vomp)

@@ -1,0 +1,249 @@
+"""Host-side op surface for the aggregation SpMM  C = Â · B  on MI355X.
+
+Mirrors the two interfaces the reference reaches its SpMM through:
+
+* B2 — ``torch.spmm(adj, dense)`` / ``torch.sparse.mm(adj, dense)`` with a
+  ``torch.sparse_coo`` fp32 ``adj`` (pygcn/gcn1.py:53, gcn2.py:92,147, gcn3.py:87,146,
+  gcn4.py:56,106, gcn5.py:90,135).  ``install()`` routes exactly that case (GPU
+  sparse fp32 × GPU dense fp32) to the HIP kernel and leaves everything else to
+  stock PyTorch, so gcn1–5 run unchanged.
+* B1 — the ``flexspmm`` autograd Function of pygcn/gcn6.py:34-62 (see dropin.py).
+
+PyTorch is plumbing here (device memory, streams, autograd); the arithmetic is
+libgcnspmm.so.  There is no CPU fallback: CPU tensors raise.
+"""
+import ctypes
+import weakref
+
+import torch
+
+from . import _lib
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _stream_ptr(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class CsrAdjacency:
+    """Device-resident CSR matrix (int32 rowptr / int32 col / fp32 val) + its cached
+    SpMM plan.  The layout is the reference's own CSR hand-off (gcn6.py:302-311:
+    ``to_sparse_csr()``, crow/col cast to int32)."""
+
+    def __init__(self, rowptr, col, val, shape, symmetric=None, chunk_nnz=0):
+        if not (rowptr.is_cuda and col.is_cuda and val.is_cuda):
+            raise _lib.GcnAmdError("CsrAdjacency needs CUDA/HIP tensors (no CPU path in gcn_amd)")
+        self.rowptr = rowptr.to(torch.int32).contiguous()
+        self.col = col.to(torch.int32).contiguous()
+        self.val = val.to(torch.float32).contiguous()
+        self.m, self.n = int(shape[0]), int(shape[1])
+        self.nnz = int(self.col.numel())
+        if self.rowptr.numel() != self.m + 1:
+            raise ValueError("rowptr must have m+1 entries")
+        if self.nnz >= 2 ** 31:
+            raise ValueError("nnz must fit int32 (row-partition the matrix first)")
+        self.symmetric = symmetric
+        self.chunk_nnz = int(chunk_nnz)
+        self._plan = None
+        self._transpose = None
+        self.device = self.val.device
+
+    # -- constructors ---------------------------------------------------------
+    @classmethod
+    def from_scipy(cls, mat, device="cuda", symmetric=None, chunk_nnz=0):
+        mat = mat.tocsr()
+        mat.sort_indices()
+        dev = torch.device(device)
+        return cls(torch.from_numpy(mat.indptr.astype("int32")).to(dev),
+                   torch.from_numpy(mat.indices.astype("int32")).to(dev),
+                   torch.from_numpy(mat.data.astype("float32")).to(dev),
+                   mat.shape, symmetric=symmetric, chunk_nnz=chunk_nnz)
+
+    @classmethod
+    def from_torch_sparse(cls, adj, symmetric=None, chunk_nnz=0):
+        """From a torch sparse COO/CSR tensor (the object pygcn builds in
+        utils.py:243-250).  COO is coalesced and converted once."""
+        if adj.layout == torch.sparse_coo:
+            adj = adj.coalesce().to_sparse_csr()
+        elif adj.layout != torch.sparse_csr:
+            raise TypeError(f"unsupported layout {adj.layout}")
+        return cls(adj.crow_indices(), adj.col_indices(), adj.values(), adj.shape,
+                   symmetric=symmetric, chunk_nnz=chunk_nnz)
+
+    # -- plan -------------------------------------------------------------------
+    @property
+    def plan(self):
+        if self._plan is None:
+            lib = _lib.load()
+            handle = ctypes.c_void_p()
+            with torch.cuda.device(self.device):
+                st = lib.gcn_spmm_plan_create(ctypes.byref(handle), _ptr(self.rowptr), self.m, self.n,
+                                              self.nnz, self.chunk_nnz, _stream_ptr(self.device))
+            _lib.check(st, "gcn_spmm_plan_create")
+            self._plan = handle
+            weakref.finalize(self, _destroy_plan, handle)
+        return self._plan
+
+    @property
+    def num_chunks(self):
+        return int(_lib.load().gcn_spmm_plan_num_chunks(self.plan))
+
+    @property
+    def chunk_size(self):
+        return int(_lib.load().gcn_spmm_plan_chunk_nnz(self.plan))
+
+    def profile_begin(self, capacity):
+        """Record HIP-event pairs around the main kernel of the next `capacity` launches."""
+        _lib.check(_lib.load().gcn_spmm_profile_begin(self.plan, int(capacity)), "gcn_spmm_profile_begin")
+        self._prof_cap = int(capacity)
+
+    def profile_end(self):
+        """→ list of per-launch main-kernel durations in ms (synchronises)."""
+        buf = (ctypes.c_float * self._prof_cap)()
+        cnt = ctypes.c_int32(0)
+        _lib.check(_lib.load().gcn_spmm_profile_end(self.plan, ctypes.cast(buf, ctypes.c_void_p),
+                                                    ctypes.cast(ctypes.byref(cnt), ctypes.c_void_p)),
+                   "gcn_spmm_profile_end")
+        return [float(buf[i]) for i in range(cnt.value)]
+
+    def transpose(self):
+        """Âᵀ as a CsrAdjacency (cached); Â itself when flagged symmetric — the
+        reference's backward reuses Â because Â is symmetric (gcn6.py:50-62)."""
+        if self.symmetric:
+            return self
+        if self._transpose is None:
+            csr = torch.sparse_csr_tensor(self.rowptr.long(), self.col.long(), self.val,
+                                          size=(self.m, self.n))
+            t = csr.to_sparse_coo().t().coalesce().to_sparse_csr()
+            self._transpose = CsrAdjacency(t.crow_indices(), t.col_indices(), t.values(),
+                                           (self.n, self.m), symmetric=False,
+                                           chunk_nnz=self.chunk_nnz)
+            self._transpose._transpose = self
+        return self._transpose
+
+    # -- the op ------------------------------------------------------------------
+    def matmul_raw(self, dense, out=None, bias=None, relu=False):
+        """C = Â·dense (+bias, ReLU) with no autograd; dense is [n x k] fp32 on the same device."""
+        if not dense.is_cuda or dense.dtype != torch.float32 or dense.dim() != 2:
+            raise _lib.GcnAmdError("dense operand must be a 2-D fp32 CUDA/HIP tensor")
+        if dense.shape[0] != self.n:
+            raise ValueError(f"shape mismatch: A is {self.m}x{self.n}, B is {tuple(dense.shape)}")
+        dense = dense.contiguous()
+        k = int(dense.shape[1])
+        if out is None:
+            out = torch.empty((self.m, k), dtype=torch.float32, device=dense.device)
+        elif not (out.is_contiguous() and out.shape == (self.m, k) and out.dtype == torch.float32):
+            raise ValueError("out must be a contiguous fp32 [m x k] tensor")
+        lib = _lib.load()
+        with torch.cuda.device(self.device):
+            if bias is None and not relu:
+                st = lib.gcn_spmm_csr_f32(self.plan, _ptr(self.rowptr), _ptr(self.col), _ptr(self.val),
+                                          _ptr(dense), _ptr(out), k, _stream_ptr(self.device))
+            else:
+                bp = _ptr(bias.contiguous()) if bias is not None else ctypes.c_void_p()
+                st = lib.gcn_spmm_csr_f32_bias_relu(self.plan, _ptr(self.rowptr), _ptr(self.col),
+                                                    _ptr(self.val), _ptr(dense), _ptr(out), bp,
+                                                    1 if relu else 0, k, _stream_ptr(self.device))
+        _lib.check(st, "gcn_spmm_csr_f32")
+        return out
+
+
+def _destroy_plan(handle):
+    try:
+        _lib.load().gcn_spmm_plan_destroy(handle)
+    except Exception:  # interpreter shutdown
+        pass
+
+
+class _SpmmFunction(torch.autograd.Function):
+    """Autograd wrapper: grad_dense = Âᵀ · grad_out (Â itself when symmetric, as in
+    gcn6.py:50-62); no gradient w.r.t. the adjacency (the reference has none either)."""
+
+    @staticmethod
+    def forward(ctx, adj, dense):
+        ctx.adj = adj
+        return adj.matmul_raw(dense)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        return None, ctx.adj.transpose().matmul_raw(grad_out.contiguous())
+
+
+def spmm(adj, dense):
+    """C = adj @ dense on the HIP kernel.  `adj` is a CsrAdjacency or a torch sparse
+    (COO/CSR) fp32 tensor on the GPU (converted and cached per tensor object)."""
+    if not isinstance(adj, CsrAdjacency):
+        adj = _cached_csr(adj)
+    return _SpmmFunction.apply(adj, dense)
+
+
+# --- routing of torch.spmm / torch.sparse.mm (interface B2) -----------------------
+_csr_cache = {}          # id(sparse tensor) -> (weakref, CsrAdjacency)
+_orig = {}
+
+
+def _cached_csr(adj):
+    key = id(adj)
+    hit = _csr_cache.get(key)
+    if hit is not None and hit[0]() is adj:
+        return hit[1]
+    csr = CsrAdjacency.from_torch_sparse(adj)
+    _csr_cache[key] = (weakref.ref(adj, lambda _r, k=key: _csr_cache.pop(k, None)), csr)
+    return csr
+
+
+def _routable(a, b):
+    return (isinstance(a, torch.Tensor) and isinstance(b, torch.Tensor)
+            and a.layout in (torch.sparse_coo, torch.sparse_csr) and a.is_cuda
+            and a.dtype == torch.float32 and a.dim() == 2
+            and b.layout == torch.strided and b.is_cuda and b.dtype == torch.float32 and b.dim() == 2
+            and not a.requires_grad)
+
+
+def install():
+    """Route ``torch.spmm`` / ``torch.sparse.mm`` for (GPU sparse fp32) × (GPU dense fp32)
+    to the HIP kernel; anything else goes to the original callables."""
+    if _orig:
+        return
+    _lib.load()  # fail loudly now, not at the first layer
+    _orig["spmm"] = torch.spmm
+    _orig["sparse_mm"] = torch.sparse.mm
+
+    def routed_spmm(a, b, *args, **kw):
+        if not args and not kw and _routable(a, b):
+            return spmm(a, b)
+        return _orig["spmm"](a, b, *args, **kw)
+
+    def routed_sparse_mm(a, b, *args, **kw):
+        if not args and not kw and _routable(a, b):
+            return spmm(a, b)
+        return _orig["sparse_mm"](a, b, *args, **kw)
+
+    torch.spmm = routed_spmm
+    torch.sparse.mm = routed_sparse_mm
+
+
+def uninstall():
+    if not _orig:
+        return
+    torch.spmm = _orig.pop("spmm")
+    torch.sparse.mm = _orig.pop("sparse_mm")
+
+
+def gather_rows(src, idx, out=None):
+    """out[r,:] = src[idx[r],:]  (permutate.cu:3-21 counterpart), fp32 on the GPU."""
+    if not (src.is_cuda and idx.is_cuda) or src.dtype != torch.float32 or src.dim() != 2:
+        raise _lib.GcnAmdError("gather_rows needs a 2-D fp32 CUDA/HIP tensor and a CUDA index")
+    src = src.contiguous()
+    idx = idx.to(torch.int32).contiguous()
+    nrows, k = int(idx.numel()), int(src.shape[1])
+    if out is None:
+        out = torch.empty((nrows, k), dtype=torch.float32, device=src.device)
+    with torch.cuda.device(src.device):
+        st = _lib.load().gcn_gather_rows_f32(_ptr(out), _ptr(src), _ptr(idx), nrows, k,
+                                             _stream_ptr(src.device))
+    _lib.check(st, "gcn_gather_rows_f32")
+    return out

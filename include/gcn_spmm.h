@@ -85,6 +85,14 @@ int gcn_spmm_csr_f32_bias_relu(gcn_spmm_plan_t* plan,
                      const float* bias_dev, int32_t relu,
                      int32_t k, void* stream);
 
+/* Live kernel timing for bench.py: between _begin and _end every gcn_spmm_csr_f32*
+ * call on this plan records a HIP event pair on its launch stream right around the
+ * MAIN kernel (up to `capacity` launches).  _end synchronises the events and returns
+ * the per-launch durations in milliseconds.  (The reference times with CUDA events
+ * from Python, pygcn/perf/dmk.py:71-117.) */
+int gcn_spmm_profile_begin(gcn_spmm_plan_t* plan, int32_t capacity);
+int gcn_spmm_profile_end(gcn_spmm_plan_t* plan, float* ms_out, int32_t* count_out);
+
 /* One-shot convenience with an internal plan cache keyed on (rowptr_dev, m, nnz);
  * this is the body of the drop-in `cuspmm` symbol. */
 int gcn_spmm_csr_f32_oneshot(const int32_t* rowptr_dev, const int32_t* col_dev,

@@ -1,0 +1,129 @@
+"""Product reorderers (C++ in libgcnspmm.so, bound through the C ABI): bit-exact against
+(i) the golden vectors recorded from the reference's compiled code, (ii) the reference build
+itself (oracle/_ref, present in the build container) on random graphs, (iii) the independent
+Python oracle; plus the invariants the reference asserts (renumber.cu:120-149,283-313)."""
+import ctypes
+import glob
+import os
+import sys
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import gcn_amd
+from gcn_amd import reorder
+from util import GOLDEN, ROOT, sym_norm_graph
+
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import reorder_oracle as ro  # noqa: E402
+
+CASES = sorted(glob.glob(os.path.join(GOLDEN, "reorder_*.npz")))
+REF_SO = os.path.join(ROOT, "oracle", "_ref", "renumber_ref.so")
+REF_ORD = os.path.join(ROOT, "oracle", "_ref", "libref_orders.so")
+
+
+@pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p)[8:-4] for p in CASES])
+def test_bit_exact_vs_reference_golden(path):
+    g = np.load(path)
+    rp, ci, va = g["rowptr"], g["col"], g["val"]
+    for which in ("total", "out", "in"):
+        for desc in (False, True):
+            assert np.array_equal(reorder.order_deg(rp, ci, which, desc),
+                                  g[f"deg_{which}_{'desc' if desc else 'asc'}"])
+    assert np.array_equal(reorder.order_rcm(rp, ci, True), g["rcm_directed"])
+    assert np.array_equal(reorder.order_rcm(rp, ci, False), g["rcm_undirected"])
+    for w in (1, 3, 5):
+        assert np.array_equal(reorder.order_gorder(rp, ci, w), g[f"gorder_w{w}"])
+    for fn in ("dfs", "gorder", "rabbit"):
+        out = getattr(reorder, fn)(rp, ci, va)
+        for key, arr in zip(("rowptr", "col", "val", "vomp"), out):
+            assert arr.dtype == g[f"{fn}_{key}"].dtype
+            assert np.array_equal(arr, g[f"{fn}_{key}"]), f"{fn} {key}"
+    out = reorder.perm_apply(rp, ci, va, g["perm_apply_in_vomp"])
+    for key, arr in zip(("rowptr", "col", "val"), out[:3]):
+        assert np.array_equal(arr, g[f"perm_apply_{key}"])
+    # apply_rank(rank) == the C-ABI gorder rewrite
+    rank = reorder.order_gorder(rp, ci, 3)
+    rp2, ci2, va2, vomp = reorder.apply_rank(rp, ci, va, rank)
+    assert np.array_equal(rp2, g["gorder_rowptr"]) and np.array_equal(ci2, g["gorder_col"])
+    assert np.array_equal(va2, g["gorder_val"]) and np.array_equal(vomp, g["gorder_vomp"])
+
+
+def _graphs():
+    yield "sym_2k", sym_norm_graph(2000, 20000, seed=10)
+    yield "sym_sparse", sym_norm_graph(3000, 4000, seed=11)
+    rng = np.random.default_rng(12)                      # skewed, asymmetric, with self-loops
+    n, e = 1500, 12000
+    u = np.minimum(n - 1, (n * rng.random(e) ** 2.5).astype(int)); v = rng.integers(0, n, e)
+    A = sp.coo_matrix((np.ones(e), (u, v)), shape=(n, n)).tocsr(); A = (A + sp.eye(n)).tocsr()
+    A.data[:] = rng.random(A.nnz) + 0.1; A.sort_indices()
+    yield "directed_skewed", (A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.astype(np.float32))
+
+
+@pytest.mark.skipif(not (os.path.exists(REF_SO) and os.path.exists(REF_ORD)),
+                    reason="oracle/_ref not built (needs /root/reference; build container only)")
+@pytest.mark.parametrize("name,graph", list(_graphs()), ids=[n for n, _ in _graphs()])
+def test_bit_exact_vs_reference_build_on_random_graphs(name, graph, capfd):
+    rp, ci, va = graph
+    n, nnz = len(rp) - 1, len(ci)
+    ref, refo = ctypes.CDLL(REF_SO), ctypes.CDLL(REF_ORD)
+    p = lambda a: ctypes.c_void_p(a.ctypes.data)
+    for fn in ("dfs", "gorder", "rabbit"):
+        a = [rp.copy(), ci.copy(), va.copy(), np.arange(n, dtype=np.int32)]
+        getattr(ref, fn)(p(a[0]), p(a[1]), p(a[2]), p(a[3]), n, n, nnz)
+        b = getattr(reorder, fn)(rp, ci, va)
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y), fn
+    for which, wname in enumerate(("total", "out", "in")):
+        for desc in (0, 1):
+            o = np.zeros(n, np.int64)
+            refo.ref_order_deg(p(rp), p(ci), n, nnz, which, desc, p(o))
+            assert np.array_equal(o, reorder.order_deg(rp, ci, wname, bool(desc)))
+    for d in (0, 1):
+        o = np.zeros(n, np.int64)
+        refo.ref_order_rcm(p(rp), p(ci), n, nnz, d, p(o))
+        assert np.array_equal(o, reorder.order_rcm(rp, ci, bool(d)))
+    for w in (2, 3, 7):
+        o = np.zeros(n, np.int64)
+        refo.ref_complete_gorder(p(rp), p(ci), n, nnz, w, p(o))
+        assert np.array_equal(o, reorder.order_gorder(rp, ci, w))
+    capfd.readouterr()      # swallow the reference's Info()/printf chatter
+
+
+def test_product_vs_python_oracle_on_a_fresh_graph():
+    rp, ci, va = sym_norm_graph(300, 1500, seed=33)
+    assert np.array_equal(reorder.order_rcm(rp, ci), ro.order_rcm(rp, ci))
+    assert np.array_equal(reorder.order_gorder(rp, ci, 3), ro.complete_gorder(rp, ci, 3))
+    for fn in ("dfs", "gorder", "rabbit"):
+        for x, y in zip(getattr(reorder, fn)(rp, ci, va), getattr(ro, fn)(rp, ci, va)):
+            assert np.array_equal(x, y), fn
+
+
+@pytest.mark.parametrize("fn", ["dfs", "gorder", "rabbit"])
+def test_renumbering_invariants(fn):
+    """what the reference asserts inline: vomp is a bijection, the rewritten CSR equals
+    A[vomp][:, vomp] exactly, columns sorted ascending within each row"""
+    rp, ci, va = sym_norm_graph(1200, 9000, seed=5)
+    n = len(rp) - 1
+    rp2, ci2, va2, vomp = getattr(reorder, fn)(rp, ci, va)
+    assert sorted(vomp.tolist()) == list(range(n))
+    A = sp.csr_matrix((va, ci, rp), shape=(n, n))
+    B = sp.csr_matrix((va2, ci2, rp2), shape=(n, n))
+    P = A[vomp][:, vomp].tocsr(); P.sort_indices()
+    assert np.array_equal(P.indptr, rp2) and np.array_equal(P.indices, ci2) and np.array_equal(P.data, va2)
+    for r in range(n):
+        seg = ci2[rp2[r]:rp2[r + 1]]
+        assert np.all(seg[1:] > seg[:-1])
+    assert B.nnz == A.nnz
+
+
+def test_gorder_rejects_graphs_the_reference_is_undefined_for():
+    """isolated vertices below the heap size: UnitHeap::ReConstruct (unitheap.cu:31-37) would
+    sort uninitialised entries — the product refuses instead of guessing."""
+    n = 6
+    rp = np.array([0, 0, 2, 4, 6, 8, 10], np.int32)       # vertex 0 has no edges at all
+    ci = np.array([2, 3, 1, 3, 1, 2, 5, 4, 4, 5], np.int32)
+    ci = np.array([2, 3, 1, 3, 1, 2, 5, 5, 4, 4], np.int32)
+    with pytest.raises(gcn_amd.GcnAmdError):
+        reorder.order_gorder(rp, ci, 3)

@@ -1,0 +1,276 @@
+"""GPU parity tests: the HIP SpMM path, called through the C ABI (libgcnspmm.so), against
+the CPU oracle (oracle/spmm_oracle.c, fp64 accumulation) on the same seeded inputs and
+against the golden outputs of the Python reference (tests/golden/gcn1_*.npz).
+
+Tolerance (BASELINE.json north_star): 1e-5 relative fp32 —
+``max|C - C*| / max|C*| <= 1e-5``.  Integer outputs are bit-exact.
+"""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import gcn_amd
+from gcn_amd import _lib, dropin, graphgen
+from util import GOLDEN, oracle_spmm, random_csr, rel_err, sym_norm_graph
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+def _adj(rowptr, col, val, m, n, **kw):
+    d = _dev()
+    return gcn_amd.CsrAdjacency(torch.from_numpy(rowptr).to(d), torch.from_numpy(col).to(d),
+                                torch.from_numpy(val).to(d), (m, n), **kw)
+
+
+def _run(rowptr, col, val, m, n, k, seed=0, **kw):
+    rng = np.random.default_rng(seed + 99)
+    B = rng.standard_normal((n, k)).astype(np.float32)
+    adj = _adj(rowptr, col, val, m, n, **kw)
+    C = adj.matmul_raw(torch.from_numpy(B).to(_dev()))
+    torch.cuda.synchronize()
+    return C.cpu().numpy(), oracle_spmm(rowptr, col, val, B), adj
+
+
+# every feature width the reference's launcher distinguishes (flexspmm.cu:510-541: 8, 16, 32,
+# <32, >32) plus the BASELINE widths 128/256/512 and awkward ones (odd, non-multiple of 64)
+@pytest.mark.parametrize("k", [1, 4, 7, 8, 16, 32, 33, 64, 100, 128, 130, 192, 256, 300, 512])
+def test_parity_feature_widths(k):
+    m = n = 3000
+    rowptr, col, val = random_csr(m, n, 60000, seed=k)
+    C, Cref, _ = _run(rowptr, col, val, m, n, k, seed=k)
+    assert rel_err(C, Cref) <= TOL
+
+
+@pytest.mark.parametrize("chunk", [64, 128, 512, 0])
+def test_parity_ragged_rows_and_chunk_sizes(chunk):
+    """empty rows (leading, trailing, in runs), rows longer than several chunks, rows
+    that end exactly on a chunk boundary"""
+    m, n, k = 2500, 4000, 128
+    rowptr, col, val = random_csr(m, n, 40000, seed=3, empty_rows=0.3,
+                                  long_rows=[(0, 0), (1, 0), (7, 3000), (8, 64), (9, 128), (1200, 2111),
+                                             (m - 1, 0), (m - 2, 0), (m - 3, 777)])
+    C, Cref, adj = _run(rowptr, col, val, m, n, k, chunk_nnz=chunk)
+    assert rel_err(C, Cref) <= TOL
+    # empty rows are written (as zeros) even though C is torch.empty
+    lens = np.diff(rowptr)
+    assert np.all(C[lens == 0] == 0.0)
+    if chunk:
+        assert adj.chunk_size == chunk
+
+
+def test_edge_cases_empty_and_tiny():
+    d = _dev()
+    # nnz == 0: all-zero output
+    rowptr = np.zeros(11, np.int32)
+    adj = _adj(rowptr, np.zeros(0, np.int32), np.zeros(0, np.float32), 10, 10)
+    C = adj.matmul_raw(torch.ones((10, 16), device=d))
+    assert C.shape == (10, 16) and float(C.abs().max()) == 0.0
+    # single non-zero
+    rowptr = np.array([0, 0, 1, 1], np.int32)
+    adj = _adj(rowptr, np.array([2], np.int32), np.array([2.5], np.float32), 3, 3)
+    B = torch.arange(9, dtype=torch.float32, device=d).reshape(3, 3)
+    C = adj.matmul_raw(B).cpu().numpy()
+    assert np.array_equal(C, np.array([[0, 0, 0], [15, 17.5, 20], [0, 0, 0]], np.float32))
+    # one row holding everything (max row length), non-square
+    n = 5000
+    rowptr = np.array([0, n], np.int32)
+    col = np.arange(n, dtype=np.int32); val = np.full(n, 1.0 / n, np.float32)
+    C, Cref, _ = _run(rowptr, col, val, 1, n, 128)
+    assert rel_err(C, Cref) <= TOL
+
+
+def test_nan_inf_do_not_leak_between_rows():
+    """a row of B holding Inf/NaN only poisons the output rows that reference it"""
+    m = n = 600
+    rowptr, col, val = random_csr(m, n, 6000, seed=11)
+    rng = np.random.default_rng(5)
+    B = rng.standard_normal((n, 128)).astype(np.float32)
+    B[0, :] = np.inf
+    adj = _adj(rowptr, col, val, m, n)
+    C = adj.matmul_raw(torch.from_numpy(B).to(_dev())).cpu().numpy()
+    touches0 = np.array([0 in col[rowptr[r]:rowptr[r + 1]] for r in range(m)])
+    assert np.all(np.isfinite(C[~touches0]))
+    assert rel_err(C[~touches0], oracle_spmm(rowptr, col, val, np.where(np.isfinite(B), B, 0))[~touches0]) <= TOL
+
+
+def test_deterministic_and_geometry_independent():
+    """bitwise identical across runs and across chunk sizes is NOT promised (different
+    partial splits), but the same plan must reproduce bit for bit (no atomics)"""
+    m = n = 4000
+    rowptr, col, val = sym_norm_graph(n, 120000, seed=2)
+    B = torch.from_numpy(np.random.default_rng(0).standard_normal((n, 128)).astype(np.float32)).to(_dev())
+    adj = _adj(rowptr, col, val, m, n)
+    C1 = adj.matmul_raw(B).clone()
+    C2 = adj.matmul_raw(B).clone()
+    assert torch.equal(C1, C2)
+    adj2 = _adj(rowptr, col, val, m, n)          # fresh plan
+    assert torch.equal(C1, adj2.matmul_raw(B))
+
+
+def test_bias_relu_epilogue():
+    m = n = 2000
+    rowptr, col, val = random_csr(m, n, 50000, seed=21, empty_rows=0.1, long_rows=[(5, 1500)])
+    rng = np.random.default_rng(1)
+    B = rng.standard_normal((n, 128)).astype(np.float32)
+    bias = rng.standard_normal(128).astype(np.float32)
+    adj = _adj(rowptr, col, val, m, n, chunk_nnz=128)
+    d = _dev()
+    C = adj.matmul_raw(torch.from_numpy(B).to(d), bias=torch.from_numpy(bias).to(d), relu=True).cpu().numpy()
+    Cref = np.maximum(oracle_spmm(rowptr, col, val, B) + bias, 0)
+    assert rel_err(C, Cref) <= TOL
+    C = adj.matmul_raw(torch.from_numpy(B).to(d), bias=torch.from_numpy(bias).to(d)).cpu().numpy()
+    assert rel_err(C, oracle_spmm(rowptr, col, val, B) + bias) <= TOL
+
+
+# --- golden vectors from the Python reference (gcn1.py:53 = torch.spmm(adj, support)) ---------
+@pytest.mark.parametrize("name", ["gcn1_tiny", "gcn1_cora_shaped"])
+def test_golden_gcn1_aggregation(name):
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    n = int(g["n"])
+    import scipy.sparse as sp
+    A = sp.coo_matrix((g["adj_val"], (g["adj_row"], g["adj_col"])), shape=(n, n)).tocsr()
+    A.sort_indices()
+    adj = gcn_amd.CsrAdjacency.from_scipy(A, device=_dev(), symmetric=True)
+    for sup, agg in (("support1", "agg1"), ("support2", "agg2")):
+        C = adj.matmul_raw(torch.from_numpy(g[sup]).to(_dev())).cpu().numpy()
+        assert rel_err(C, g[agg]) <= TOL, (name, agg)
+
+
+def test_golden_gcn1_forward_through_routed_torch_spmm():
+    """2-layer GCN forward exactly as gcn1.py:40-58,102-126 writes it (torch.spmm on a sparse
+    COO adj) with gcn_amd.install() active; compared with the reference's recorded output."""
+    g = np.load(os.path.join(GOLDEN, "gcn1_cora_shaped.npz"))
+    n, d = int(g["n"]), _dev()
+    adj = torch.sparse_coo_tensor(torch.from_numpy(np.vstack([g["adj_row"], g["adj_col"]]).astype(np.int64)),
+                                  torch.from_numpy(g["adj_val"]), (n, n)).to(d)
+    X = torch.sparse_coo_tensor(torch.from_numpy(np.vstack([g["x_row"], g["x_col"]]).astype(np.int64)),
+                                torch.from_numpy(g["x_val"]), (n, int(g["nfeat"]))).to(d).to_dense()
+    w1, b1, w2, b2 = (torch.from_numpy(g[k]).to(d) for k in ("w1", "b1", "w2", "b2"))
+    gcn_amd.install()
+    try:
+        h = torch.spmm(adj, torch.mm(X, w1)) + b1
+        h = torch.relu(h)
+        out = torch.log_softmax(torch.sparse.mm(adj, torch.mm(h, w2)) + b2, dim=1)
+        assert id(adj) in gcn_amd.spmm.__globals__["_csr_cache"], "torch.spmm was not routed to the HIP path"
+    finally:
+        gcn_amd.uninstall()
+    assert rel_err(out.cpu().numpy(), g["out"]) <= TOL
+
+
+def test_autograd_backward_matches_transpose():
+    m, n, k = 700, 900, 64
+    rowptr, col, val = random_csr(m, n, 9000, seed=8)
+    adj = _adj(rowptr, col, val, m, n, symmetric=False)
+    rng = np.random.default_rng(2)
+    B = torch.from_numpy(rng.standard_normal((n, k)).astype(np.float32)).to(_dev()).requires_grad_(True)
+    G = rng.standard_normal((m, k)).astype(np.float32)
+    C = gcn_amd.spmm(adj, B)
+    C.backward(torch.from_numpy(G).to(_dev()))
+    import scipy.sparse as sp
+    At = sp.csr_matrix((val, col, rowptr), shape=(m, n)).T.tocsr(); At.sort_indices()
+    gref = oracle_spmm(At.indptr.astype(np.int32), At.indices.astype(np.int32), At.data.astype(np.float32), G)
+    assert rel_err(B.grad.cpu().numpy(), gref) <= TOL
+
+
+# --- the gcn6 drop-in symbols (interface B1) ------------------------------------------------
+def test_dropin_csr2tile_flexspmm_permutate_cuspmm():
+    n = 3000
+    rowptr, col, val = sym_norm_graph(n, 40000, seed=4)
+    nnz = len(col)
+    d = _dev()
+    t_rp, t_ci, t_va = torch.from_numpy(rowptr.copy()), torch.from_numpy(col.copy()), torch.from_numpy(val.copy())
+    vo_mp = torch.arange(n, dtype=torch.int32)
+    seg_rowPtr, segNzCV, segVoMap, tail, nxt, n_segs = dropin.csr2tile(t_rp, t_ci, t_va, n, n, nnz, vo_mp)
+    assert seg_rowPtr.numel() == 9 * int(n_segs[0]) and segVoMap.numel() == 8 * int(n_segs[0])
+    assert tail.numel() == 256 and nxt.numel() == 256               # defect D2: never 257 entries
+    dev = [t.to(d) for t in (seg_rowPtr, segNzCV, segVoMap, tail, nxt)]
+    rng = np.random.default_rng(3)
+    for k in (16, 128):
+        X = rng.standard_normal((n, k)).astype(np.float32)
+        Xd = torch.from_numpy(X).to(d).requires_grad_(True)
+        out = dropin.flexspmm.apply(dev[0], dev[1], dev[2], n, n, int(n_segs[0]), dev[3], dev[4], Xd)
+        Cref = oracle_spmm(rowptr, col, val, X)
+        assert rel_err(out.detach().cpu().numpy(), Cref) <= TOL
+        G = rng.standard_normal((n, k)).astype(np.float32)
+        out.backward(torch.from_numpy(G).to(d))
+        assert rel_err(Xd.grad.cpu().numpy(), oracle_spmm(rowptr, col, val, G)) <= TOL   # Â symmetric
+    # cuspmm symbol (cuspmm.cu:23-24)
+    X = rng.standard_normal((n, 64)).astype(np.float32)
+    C = torch.empty((n, 64), device=d)
+    dropin.cuspmm(t_rp.to(d), t_ci.to(d), t_va.to(d), torch.from_numpy(X).to(d), C, n, n, nnz, 64)
+    torch.cuda.synchronize()
+    assert rel_err(C.cpu().numpy(), oracle_spmm(rowptr, col, val, X)) <= TOL
+    # permutate symbol: B[r,:] <- B[vomp[r],:] in place, labels untouched (permutate.cu:17,35)
+    perm = rng.permutation(n).astype(np.int32)
+    Xd = torch.from_numpy(X).to(d).clone()
+    labels = torch.arange(n, dtype=torch.int32, device=d)
+    dropin.permutate(Xd, torch.from_numpy(perm).to(d), labels, n, n, 64)
+    assert np.array_equal(Xd.cpu().numpy(), X[perm])                 # bit-exact copy
+    assert torch.equal(labels, torch.arange(n, dtype=torch.int32, device=d))
+
+
+def test_gather_rows_bit_exact():
+    rng = np.random.default_rng(0)
+    for k in (7, 128, 130):
+        X = rng.standard_normal((1000, k)).astype(np.float32)
+        idx = rng.integers(0, 1000, 2500).astype(np.int32)
+        out = gcn_amd.gather_rows(torch.from_numpy(X).to(_dev()), torch.from_numpy(idx).to(_dev()))
+        assert np.array_equal(out.cpu().numpy(), X[idx])
+
+
+def test_reorder_then_spmm_is_a_permutation_of_the_result():
+    """P·Â·Pᵀ · (P·B) = P·(Â·B): renumbering + feature permutation (gcn6.py steps 1 and 4)
+    reproduce the un-reordered result up to row order."""
+    n, k = 2000, 128
+    rowptr, col, val = sym_norm_graph(n, 30000, seed=6)
+    X = np.random.default_rng(1).standard_normal((n, k)).astype(np.float32)
+    base = oracle_spmm(rowptr, col, val, X)
+    for fn in (gcn_amd.reorder.gorder, gcn_amd.reorder.dfs, gcn_amd.reorder.rabbit):
+        rp2, ci2, va2, vomp = fn(rowptr, col, val)
+        adj = _adj(rp2, ci2, va2, n, n, symmetric=True)
+        Xp = gcn_amd.gather_rows(torch.from_numpy(X).to(_dev()), torch.from_numpy(vomp).to(_dev()))
+        C = adj.matmul_raw(Xp).cpu().numpy()
+        assert rel_err(C, base[vomp]) <= TOL
+
+
+# --- BASELINE-size checks through size-independent properties ---------------------------------
+def test_full_size_reddit_shape_properties():
+    """Reddit-shaped graph at full size (n = 232 965, nnz ≈ 114.85 M, k = 128):
+    (i) sampled rows against the fp64 oracle, (ii) Â·1 = row sums, (iii) linearity."""
+    d = _dev()
+    rowptr, col, val, n = graphgen.make_graph("reddit", device=d, seed=1)
+    nnz = int(col.numel())
+    assert n == 232965 and abs(nnz - 114.85e6) < 0.05e6
+    adj = gcn_amd.CsrAdjacency(rowptr, col, val, (n, n), symmetric=True)
+    k = 128
+    B = graphgen.random_features(n, k, seed=2, device=d)
+    C = adj.matmul_raw(B)
+    # (i) 4096 sampled rows vs fp64
+    rows = np.random.default_rng(0).choice(n, 4096, replace=False); rows.sort()
+    rp = rowptr.cpu().numpy()
+    seg = [np.arange(rp[r], rp[r + 1]) for r in rows]
+    idx = torch.from_numpy(np.concatenate(seg)).to(d)
+    sub_rp = np.zeros(len(rows) + 1, np.int32); sub_rp[1:] = np.cumsum([len(s) for s in seg])
+    Cref = oracle_spmm(sub_rp, col[idx].cpu().numpy(), val[idx].cpu().numpy(), B.cpu().numpy())
+    assert rel_err(C[torch.from_numpy(rows).to(d)].cpu().numpy(), Cref) <= TOL
+    # (ii) Â·1: every output column equals the row sum of Â
+    ones = torch.ones((n, 64), device=d)
+    rs = adj.matmul_raw(ones)
+    rowsum = torch.zeros(n, dtype=torch.float64, device=d).index_add_(
+        0, torch.repeat_interleave(torch.arange(n, device=d), (rowptr[1:] - rowptr[:-1]).long()), val.double())
+    assert float((rs[:, 0].double() - rowsum).abs().max() / rowsum.abs().max()) <= TOL
+    assert torch.equal(rs[:, 0], rs[:, 63])
+    # (iii) linearity: Â(2B + B') = 2ÂB + ÂB'
+    B2 = graphgen.random_features(n, k, seed=3, device=d)
+    lhs = adj.matmul_raw(2 * B + B2)
+    rhs = 2 * C + adj.matmul_raw(B2)
+    assert float((lhs - rhs).abs().max() / rhs.abs().max()) <= TOL
