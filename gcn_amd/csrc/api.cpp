@@ -26,6 +26,7 @@ struct gcn_spmm_plan {
   // live kernel timing (gcn_spmm_profile_begin/_end)
   std::vector<hipEvent_t> ev;   // 2 per recorded launch
   int prof_cap, prof_n;
+  int tile_cols;                // 0 = auto
 };
 
 namespace {
@@ -54,6 +55,18 @@ int auto_chunk_nnz(long long nnz, int cu) {
   if (t < 64) t = 64;
   if (t > 512) t = 512;
   return (int)t;
+}
+
+// Feature-column tile per pass.  Measured on MI355X (profiles/r01_sweep_tiles_*.txt): when one
+// 64-column slice of B (n x 256 B) sits well inside the 256 MiB Infinity Cache, k/64 narrow
+// passes beat one wide pass by 3-6 % (Reddit-shaped, n = 233 k); when it does not (products-
+// shaped, n = 2.4 M) the widest tile wins by 6-7 %.
+int auto_tile_cols(long long n, int k) {
+  if (k <= 64) return 0;
+  const long long budget = 128LL << 20;          // half of the Infinity Cache
+  if (n * 256 <= budget) return 64;
+  if (n * 512 <= budget && k > 128) return 128;
+  return 0;                                      // widest tile k allows (<= 256 columns)
 }
 
 int ensure_ws(gcn_spmm_plan* p, int k) {
@@ -109,6 +122,7 @@ int gcn_spmm_plan_create(gcn_spmm_plan_t** out, const int32_t* rowptr_dev, int32
   p->nchunks = (int)(((long long)nnz + p->T - 1) / p->T);
   p->chunk_row = nullptr; p->ws = nullptr; p->ws_bytes = 0; p->cu_count = cu;
   p->prof_cap = p->prof_n = 0;
+  p->tile_cols = 0;
   (void)hipGetDevice(&p->device);
   if (p->nchunks > 0) {
     if (hipMalloc((void**)&p->chunk_row, sizeof(int) * (size_t)p->nchunks) != hipSuccess) {
@@ -155,12 +169,19 @@ int gcn_spmm_csr_f32_bias_relu(gcn_spmm_plan_t* p, const int32_t* rowptr, const 
   a.chunk_row = p->chunk_row; a.bias = bias; a.relu = relu ? 1 : 0;
   a.nchunks = p->nchunks; a.T = p->T; a.m = p->m; a.nnz = p->nnz; a.k = k;
   a.nnz_dev = nullptr; a.nchunks_grid = p->nchunks;
+  a.tile_cols = p->tile_cols ? p->tile_cols : auto_tile_cols(p->n, k);
   if (p->prof_cap > 0 && p->prof_n < p->prof_cap) {
     a.ev_start = p->ev[2 * p->prof_n];
     a.ev_stop = p->ev[2 * p->prof_n + 1];
     ++p->prof_n;
   }
   return gcn::launch_spmm(a, p->cu_count, (hipStream_t)stream) == hipSuccess ? GCN_OK : GCN_ERR_HIP;
+}
+
+int gcn_spmm_plan_set_tile_cols(gcn_spmm_plan_t* p, int32_t cols) {
+  if (!p || !(cols == 0 || cols == 64 || cols == 128 || cols == 256)) return GCN_ERR_INVALID_ARG;
+  p->tile_cols = cols;
+  return GCN_OK;
 }
 
 int gcn_spmm_profile_begin(gcn_spmm_plan_t* p, int32_t capacity) {
@@ -227,6 +248,7 @@ int gcn_spmm_csr_f32_oneshot(const int32_t* rowptr, const int32_t* col, const fl
   a.chunk_row = p->chunk_row; a.bias = nullptr; a.relu = 0;
   a.nchunks = p->nchunks; a.T = p->T; a.m = m; a.nnz = nnz; a.k = k;
   a.nnz_dev = nullptr; a.nchunks_grid = p->nchunks;
+  a.tile_cols = auto_tile_cols(n, k);
   return gcn::launch_spmm(a, cu, (hipStream_t)stream) == hipSuccess ? GCN_OK : GCN_ERR_HIP;
 }
 
@@ -408,7 +430,7 @@ void csr2tile(int* rowPtr, int* colIdx, float* vals, int m, int n, int nnz, int*
 
 void flexspmm(int* seg_rowPtr, float* segNzCV, int* segVoMap, int* grouped_tailSeg, int* next_seg,
               int m, int n, int k, int n_segs, float* B, float* C) {
-  (void)grouped_tailSeg; (void)next_seg; (void)n;
+  (void)grouped_tailSeg; (void)next_seg;
   static gcn_spmm_plan scratch{};
   if (m <= 0 || k <= 0) return;
   const int cu = cu_count_cached();
@@ -427,6 +449,7 @@ void flexspmm(int* seg_rowPtr, float* segNzCV, int* segVoMap, int* grouped_tailS
   a.nchunks = 0; a.T = T; a.m = m; a.nnz = 0; a.k = k;
   a.nnz_dev = seg_rowPtr + m;            // exact nnz lives in rowPtr[m]
   a.nchunks_grid = nchunks_ub;
+  a.tile_cols = auto_tile_cols(n, k);
   const hipError_t e = gcn::launch_spmm(a, cu, (hipStream_t) nullptr);   // legacy default stream
   if (e != hipSuccess) die("flexspmm launch", e);
 }

@@ -25,6 +25,7 @@ struct SpmmArgs {
   // optional HIP events recorded on the launch stream right before / after the MAIN
   // kernel (not the fix-up) — the live kernel timing bench.py reports (null = off)
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+  int tile_cols = 0;       // feature-column tile per pass: 0 auto, else 64 / 128 / 256
 };
 
 hipError_t launch_plan_chunk_rows(const int* rowptr, int m, int T, int nchunks,
@@ -32,6 +33,6 @@ hipError_t launch_plan_chunk_rows(const int* rowptr, int m, int T, int nchunks,
 hipError_t launch_spmm(const SpmmArgs& a, int cu_count, hipStream_t s);
 hipError_t launch_gather_rows(float* dst, const float* src, const int* idx, int nrows, int k,
                               hipStream_t s);
-int pick_vec(int k, const void* B, const void* C, const void* P);
+int pick_vec(int k, int tile_cols, const void* B, const void* C, const void* P);
 
 }  // namespace gcn

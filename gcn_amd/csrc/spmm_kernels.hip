@@ -85,7 +85,7 @@ spmm_chunk_kernel(const int* __restrict__ g_rowptr, const int* __restrict__ g_co
                   float* __restrict__ g_C, float* __restrict__ g_P,
                   const int* __restrict__ g_chunk_row, const float* __restrict__ g_bias,
                   const int* __restrict__ g_nnz_dev,
-                  int relu, int nchunks, int T, int m, int nnz, int kk) {
+                  int relu, int nchunks, int T, int m, int nnz, int kk, int col_tile) {
   // drop-in (flexspmm) mode: the host does not know nnz; it lives in rowptr[m] and
   // the values follow the column indices in one buffer (api.cpp, csr2tile layout)
   if (g_nnz_dev) {
@@ -114,7 +114,7 @@ spmm_chunk_kernel(const int* __restrict__ g_rowptr, const int* __restrict__ g_co
   const int c_lo = (int)(((long long)a.nchunks * xcd) >> 3);
   const int c_hi = (int)(((long long)a.nchunks * (xcd + 1)) >> 3);
 
-  const int  fcol   = blockIdx.y * (64 * VEC) + lane * VEC;   // first feature column of this lane
+  const int  fcol   = col_tile * (64 * VEC) + lane * VEC;   // first feature column of this lane
   const bool active = fcol < a.k;
   const float* __restrict__ Bl = a.B + (active ? fcol : 0);
   const size_t k = (size_t)a.k;
@@ -294,20 +294,29 @@ hipError_t launch_plan_chunk_rows(const int* rowptr, int m, int T, int nchunks,
 
 template <int VEC, int U>
 static hipError_t launch_main(const SpmmArgs& a, int nblocks, bool epi, hipStream_t s) {
+  // One launch per 64*VEC-column tile, back to back on the stream: a pass only touches its
+  // own column slice of B, so the gathered working set per pass is n*64*VEC*4 bytes — the
+  // narrower the slice, the larger the share of it that stays in L2 / Infinity Cache.
   const int tiles = (a.k + 64 * VEC - 1) / (64 * VEC);
-  dim3 grid(nblocks, tiles), block(256);
+  dim3 grid(nblocks), block(256);
 #define GCN_MAIN_ARGS a.rowptr, a.col, a.val, a.B, a.C, a.P, a.chunk_row, a.bias, a.nnz_dev, \
-                      a.relu, a.nchunks, a.T, a.m, a.nnz, a.k
-  if (epi) spmm_chunk_kernel<VEC, U, true><<<grid, block, 0, s>>>(GCN_MAIN_ARGS);
-  else     spmm_chunk_kernel<VEC, U, false><<<grid, block, 0, s>>>(GCN_MAIN_ARGS);
+                      a.relu, a.nchunks, a.T, a.m, a.nnz, a.k, t
+  for (int t = 0; t < tiles; ++t) {
+    if (epi) spmm_chunk_kernel<VEC, U, true><<<grid, block, 0, s>>>(GCN_MAIN_ARGS);
+    else     spmm_chunk_kernel<VEC, U, false><<<grid, block, 0, s>>>(GCN_MAIN_ARGS);
+  }
 #undef GCN_MAIN_ARGS
   return hipGetLastError();
 }
 
-int pick_vec(int k, const void* B, const void* C, const void* P) {
+// floats per lane (1, 2 or 4): the column tile is 64*VEC wide.  tile_cols = 0 picks the
+// widest tile that k fills; otherwise the requested tile width (64 / 128 / 256) is honoured
+// when k and the pointers allow the vector width.
+int pick_vec(int k, int tile_cols, const void* B, const void* C, const void* P) {
   const uintptr_t al = (uintptr_t)B | (uintptr_t)C | (uintptr_t)P;
-  if (k % 4 == 0 && k > 128 && (al & 15) == 0) return 4;
-  if (k % 2 == 0 && k > 64 && (al & 7) == 0) return 2;
+  int want = tile_cols > 0 ? tile_cols / 64 : (k > 128 ? 4 : (k > 64 ? 2 : 1));
+  if (want >= 4 && k % 4 == 0 && (al & 15) == 0) return 4;
+  if (want >= 2 && k % 2 == 0 && (al & 7) == 0) return 2;
   return 1;
 }
 
@@ -329,7 +338,7 @@ hipError_t launch_spmm(const SpmmArgs& a, int cu_count, hipStream_t s) {
   nblocks = (nblocks + 7) & ~7;
   hipError_t e;
   if (a.ev_start && (e = hipEventRecord(a.ev_start, s)) != hipSuccess) return e;
-  switch (pick_vec(a.k, a.B, a.C, a.P)) {
+  switch (pick_vec(a.k, a.tile_cols, a.B, a.C, a.P)) {
     case 4:  e = launch_main<4, 4>(a, nblocks, epi, s); break;
     case 2:  e = launch_main<2, 8>(a, nblocks, epi, s); break;
     default: e = launch_main<1, 8>(a, nblocks, epi, s); break;

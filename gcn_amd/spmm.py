@@ -95,6 +95,10 @@ class CsrAdjacency:
     def chunk_size(self):
         return int(_lib.load().gcn_spmm_plan_chunk_nnz(self.plan))
 
+    def set_tile_cols(self, cols):
+        """Feature-column tile per kernel pass (0 auto, 64, 128, 256)."""
+        _lib.check(_lib.load().gcn_spmm_plan_set_tile_cols(self.plan, int(cols)), "gcn_spmm_plan_set_tile_cols")
+
     def profile_begin(self, capacity):
         """Record HIP-event pairs around the main kernel of the next `capacity` launches."""
         _lib.check(_lib.load().gcn_spmm_profile_begin(self.plan, int(capacity)), "gcn_spmm_profile_begin")

@@ -85,9 +85,14 @@ int gcn_spmm_csr_f32_bias_relu(gcn_spmm_plan_t* plan,
                      const float* bias_dev, int32_t relu,
                      int32_t k, void* stream);
 
+/* Feature-column tile per kernel pass: 0 = automatic, else 64, 128 or 256 columns.  A k-wide
+ * SpMM runs as ceil(k/tile) back-to-back passes, each gathering only its column slice of B
+ * (smaller per-pass working set -> more of it stays in L2 / Infinity Cache). */
+int gcn_spmm_plan_set_tile_cols(gcn_spmm_plan_t* plan, int32_t cols);
+
 /* Live kernel timing for bench.py: between _begin and _end every gcn_spmm_csr_f32*
  * call on this plan records a HIP event pair on its launch stream right around the
- * MAIN kernel (up to `capacity` launches).  _end synchronises the events and returns
+ * MAIN kernel passes of one SpMM (up to `capacity` SpMM calls).  _end synchronises the events and returns
  * the per-launch durations in milliseconds.  (The reference times with CUDA events
  * from Python, pygcn/perf/dmk.py:71-117.) */
 int gcn_spmm_profile_begin(gcn_spmm_plan_t* plan, int32_t capacity);

@@ -118,12 +118,19 @@ def test_renumbering_invariants(fn):
     assert B.nnz == A.nnz
 
 
-def test_gorder_rejects_graphs_the_reference_is_undefined_for():
-    """isolated vertices below the heap size: UnitHeap::ReConstruct (unitheap.cu:31-37) would
-    sort uninitialised entries — the product refuses instead of guessing."""
-    n = 6
-    rp = np.array([0, 0, 2, 4, 6, 8, 10], np.int32)       # vertex 0 has no edges at all
-    ci = np.array([2, 3, 1, 3, 1, 2, 5, 4, 4, 5], np.int32)
-    ci = np.array([2, 3, 1, 3, 1, 2, 5, 5, 4, 4], np.int32)
-    with pytest.raises(gcn_amd.GcnAmdError):
-        reorder.order_gorder(rp, ci, 3)
+def test_gorder_with_isolated_vertices():
+    """Vertices with no edge at all (no self-loop either): RCM ranks them last, so they sit
+    above the heap range and Gorder appends them at the end (order_gorder.cu:42-43,78) — the
+    case UnitHeap::ReConstruct (unitheap.cu:31-37) silently relies on.  Product == Python oracle
+    (== the reference build when present)."""
+    rp = np.array([0, 0, 2, 4, 6, 6, 8, 10], np.int32)      # vertices 0 and 4 are isolated
+    ci = np.array([2, 3, 1, 3, 1, 2, 6, 6, 5, 5], np.int32)
+    n, nnz = len(rp) - 1, len(ci)
+    got = reorder.order_gorder(rp, ci, 3)
+    assert np.array_equal(got, ro.complete_gorder(rp, ci, 3))
+    assert sorted(got.tolist()) == list(range(n))
+    if os.path.exists(REF_ORD):
+        o = np.zeros(n, np.int64)
+        ctypes.CDLL(REF_ORD).ref_complete_gorder(ctypes.c_void_p(rp.ctypes.data), ctypes.c_void_p(ci.ctypes.data),
+                                                 n, nnz, 3, ctypes.c_void_p(o.ctypes.data))
+        assert np.array_equal(got, o)

@@ -50,6 +50,20 @@ def test_parity_feature_widths(k):
     assert rel_err(C, Cref) <= TOL
 
 
+@pytest.mark.parametrize("k,tile", [(128, 64), (128, 128), (256, 64), (256, 128), (256, 256), (512, 64),
+                                    (512, 256), (300, 64), (300, 128), (300, 256), (130, 128), (33, 64)])
+def test_parity_column_tile_passes(k, tile):
+    """a k-wide SpMM as ceil(k/tile) sequential column-slice passes (gcn_spmm_plan_set_tile_cols)"""
+    m = n = 2000
+    rowptr, col, val = random_csr(m, n, 40000, seed=k + tile, empty_rows=0.05, long_rows=[(3, 1800)])
+    rng = np.random.default_rng(k)
+    B = rng.standard_normal((n, k)).astype(np.float32)
+    adj = _adj(rowptr, col, val, m, n, chunk_nnz=128)
+    adj.set_tile_cols(tile)
+    C = adj.matmul_raw(torch.from_numpy(B).to(_dev())).cpu().numpy()
+    assert rel_err(C, oracle_spmm(rowptr, col, val, B)) <= TOL
+
+
 @pytest.mark.parametrize("chunk", [64, 128, 512, 0])
 def test_parity_ragged_rows_and_chunk_sizes(chunk):
     """empty rows (leading, trailing, in runs), rows longer than several chunks, rows
