@@ -79,6 +79,25 @@ class RowShardedAdjacency:
     def new_buffer(self, k, device, dtype=torch.float32):
         return torch.zeros((self.world * self.max_rows, k), dtype=dtype, device=device)
 
+    def _all_gather(self, out_padded, slot, group, async_op):
+        try:
+            return dist.all_gather_into_tensor(out_padded, slot, group=group, async_op=async_op)
+        except (RuntimeError, NotImplementedError):         # backends without the flat form
+            views = [out_padded[p * self.max_rows: (p + 1) * self.max_rows] for p in range(self.world)]
+            return dist.all_gather(views, slot.clone(), group=group, async_op=async_op)
+
+    def layer_async(self, H_padded, out_padded, group=None):
+        """Like layer(), but the all-gather is only ENQUEUED (on the communicator's stream, behind
+        the SpMM that fills the slot); returns the Work handle (None for world == 1).  The caller
+        waits on it before the next read of out_padded — this is what lets the all-gather of one
+        column plane overlap the SpMM of the next (PipelinedAggregation)."""
+        slot = out_padded[self.rank * self.max_rows: (self.rank + 1) * self.max_rows]
+        if self.rows:
+            self.local.matmul_raw(H_padded, out=slot[: self.rows])
+        if self.world > 1:
+            return self._all_gather(out_padded, slot, group, True)
+        return None
+
     def layer(self, H_padded, out_padded, group=None):
         """out = Â · H for the whole graph, in the padded layout, on every rank:
         local row-block SpMM into this rank's slot, then one in-place all-gather."""
@@ -93,3 +112,50 @@ class RowShardedAdjacency:
                 views = [out_padded[p * self.max_rows: (p + 1) * self.max_rows] for p in range(self.world)]
                 dist.all_gather(views, slot.clone(), group=group)
         return out_padded
+
+
+class PipelinedAggregation:
+    """Repeated aggregation layers H ← Â·H on a row-sharded Â with the exchange hidden.
+
+    The k feature columns are kept as independent PLANES of ≤ `plane_cols` columns (each plane a
+    padded [world·max_rows, cols] buffer pair).  Â·H acts on every column independently, so
+    plane p of layer l+1 depends only on the gathered plane p of layer l: while RCCL all-gathers
+    plane p over xGMI on its own stream, the compute stream already runs the SpMM of plane p+1
+    (and, at the layer seam, plane 0 of the next layer).  Per layer every rank still does all of
+    its row-block SpMM work and one all-gather per plane; only the waiting is gone.  Plane width 64
+    is also the kernel's preferred column tile when n·256 B fits the Infinity Cache.
+    """
+
+    def __init__(self, shard, k, device, plane_cols=64, group=None):
+        self.shard, self.k, self.group = shard, int(k), group
+        self.widths = [min(plane_cols, k - c) for c in range(0, k, plane_cols)]
+        self.src = [shard.new_buffer(w, device) for w in self.widths]
+        self.dst = [shard.new_buffer(w, device) for w in self.widths]
+        self.pending = [None] * len(self.widths)
+
+    def load(self, H):
+        """global [n, k] features → the planes' source buffers"""
+        c = 0
+        for p, w in enumerate(self.widths):
+            self.src[p].copy_(self.shard.to_padded(H[:, c:c + w].contiguous()))
+            c += w
+
+    def step(self):
+        """one aggregation layer over all planes (all-gathers left in flight)"""
+        for p in range(len(self.widths)):
+            if self.pending[p] is not None:
+                self.pending[p].wait()              # the gather that produced src[p]
+                self.pending[p] = None
+            self.pending[p] = self.shard.layer_async(self.src[p], self.dst[p], self.group)
+            self.src[p], self.dst[p] = self.dst[p], self.src[p]
+
+    def finish(self):
+        for p, w in enumerate(self.pending):
+            if w is not None:
+                w.wait()
+                self.pending[p] = None
+
+    def result(self):
+        """global [n, k] view of the current layer output (waits for outstanding gathers)"""
+        self.finish()
+        return torch.cat([self.shard.from_padded(b) for b in self.src], 1)

@@ -12,7 +12,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from gcn_amd.dist import RowShardedAdjacency, partition_rows
+from gcn_amd.dist import PipelinedAggregation, RowShardedAdjacency, partition_rows
 from util import oracle_spmm, sym_norm_graph
 
 
@@ -56,6 +56,13 @@ def _worker(rank, world, port, balance, q):
         ref2 = oracle_spmm(rp, ci, va, ref1, fp64=False)
         # a row partition keeps every row's summation order → bit-identical to the unsharded run
         ok = np.array_equal(got1, ref1) and np.array_equal(got2, ref2)
+        # the pipelined form (column planes, all-gathers left in flight) over three layers
+        pipe = PipelinedAggregation(shard, k, "cpu", plane_cols=16)
+        pipe.load(H)
+        for _ in range(3):
+            pipe.step()
+        ref3 = oracle_spmm(rp, ci, va, ref2, fp64=False)
+        ok = ok and len(pipe.widths) == 2 and np.array_equal(pipe.result().numpy(), ref3)
         q.put((rank, bool(ok), int(shard.local_nnz), int(shard.rows)))
     finally:
         dist.destroy_process_group()

@@ -288,3 +288,37 @@ def test_full_size_reddit_shape_properties():
     lhs = adj.matmul_raw(2 * B + B2)
     rhs = 2 * C + adj.matmul_raw(B2)
     assert float((lhs - rhs).abs().max() / rhs.abs().max()) <= TOL
+
+
+# --- the N>1 building blocks on the real kernel (the collective itself is covered by the gloo
+# --- tests in test_dist.py; one box has one GPU) ------------------------------------------------
+def test_row_sharded_blocks_reproduce_the_single_gpu_result_bitwise():
+    from gcn_amd.dist import PipelinedAggregation, RowShardedAdjacency
+    n, k, d = 6000, 128, _dev()
+    rowptr, col, val = sym_norm_graph(n, 150000, seed=9)
+    t = [torch.from_numpy(x).to(d) for x in (rowptr, col, val)]
+    H = torch.from_numpy(np.random.default_rng(4).standard_normal((n, k)).astype(np.float32)).to(d)
+    full = gcn_amd.CsrAdjacency(t[0], t[1], t[2], (n, n), symmetric=True, chunk_nnz=64)
+    ref = full.matmul_raw(H)
+    for world in (2, 3, 8):
+        shards = [RowShardedAdjacency(t[0], t[1], t[2], n, r, world,
+                                      lambda rp, ci, va, shape: gcn_amd.CsrAdjacency(rp, ci, va, shape, chunk_nnz=64))
+                  for r in range(world)]
+        Hp = shards[0].to_padded(H)
+        out = shards[0].new_buffer(k, d)
+        for r, sh in enumerate(shards):                      # what each rank writes into its slot
+            sh.local.matmul_raw(Hp, out=out[r * sh.max_rows: r * sh.max_rows + sh.rows])
+        got = shards[0].from_padded(out)
+        assert rel_err(got.cpu().numpy(), oracle_spmm(rowptr, col, val, H.cpu().numpy())) <= TOL
+        assert sum(sh.local_nnz for sh in shards) == len(col)
+    # world = 1 pipeline (planes of 64 columns) over 3 layers == 3 chained single-GPU SpMMs per plane
+    sh = RowShardedAdjacency(t[0], t[1], t[2], n, 0, 1, lambda rp, ci, va, shape: gcn_amd.CsrAdjacency(rp, ci, va, shape))
+    pipe = PipelinedAggregation(sh, k, d, plane_cols=64)
+    pipe.load(H)
+    for _ in range(3):
+        pipe.step()
+    chain = H
+    for _ in range(3):
+        chain = full.matmul_raw(chain)
+    assert rel_err(pipe.result().cpu().numpy(), chain.cpu().numpy()) <= TOL
+    assert rel_err(ref.cpu().numpy(), oracle_spmm(rowptr, col, val, H.cpu().numpy())) <= TOL
