@@ -37,6 +37,19 @@ def algorithmic_bytes(m, nnz, k):
     return nnz * (4 + 4 + 4 * k) + (m + 1) * 4 + m * k * 4
 
 
+def pmc_traffic(graph, k, passes):
+    """HBM-side bytes per main-kernel launch from the committed PMC summary (collected in separate
+    `rocprofv3 --pmc` passes of this same bench command, tools/pmc_summary.py), or None when the
+    summary was taken for a different configuration."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
+        if d.get("graph") == graph and d.get("k") == k and d.get("launches_per_spmm") == passes:
+            return int(d["traffic_bytes_per_launch"])
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
 def cpu_baseline(rowptr, col, val, n, k, seed):
     """pygcn's CPU path: torch.spmm(adj_sparse_coo_fp32, dense) exactly as gcn1.py:53 issues it,
     on this box's host cores (baseline only; bounded to ~30 s)."""
@@ -76,6 +89,8 @@ def main():
     ap.add_argument("--k", type=int, default=K_FEAT)
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the graph (debug only; invalidates the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-shard", action="store_true",
+                    help="debug: run the row-sharded pipelined path even with one rank (no collective)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -98,7 +113,8 @@ def main():
     nnz, k = int(col.numel()), args.k
     H = graphgen.random_features(n, k, seed=2, device=dev)
 
-    if world == 1:
+    sharded = world > 1 or args.force_shard
+    if not sharded:
         adj = gcn_amd.CsrAdjacency(rowptr, col, val, (n, n), symmetric=True)
         out = torch.empty((n, k), dtype=torch.float32, device=dev)
 
@@ -132,7 +148,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    if world > 1:
+    if sharded:
         pipe.finish()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -146,9 +162,14 @@ def main():
     # ---- roofline of the dominant kernel (spmm_chunk_kernel), this rank's launches ---------
     # (N = 1: one timed interval per SpMM = all column passes of the main kernel; N > 1: one per
     #  64-column plane SpMM of this rank's row block)
-    kavg = sum(kernel_ms) / max(len(kernel_ms), 1) * 1e-3
-    balg = algorithmic_bytes(local_m, local_nnz, k if world == 1 else min(k, 64))
+    kp = k if not sharded else min(k, 64)                 # columns per timed SpMM
+    passes = local_adj.num_passes(kp)                     # main-kernel launches per timed SpMM
+    spmm_avg = sum(kernel_ms) / max(len(kernel_ms), 1) * 1e-3
+    kavg = spmm_avg / passes                              # per LAUNCH, what rocprofv3 --stats averages
+    balg = algorithmic_bytes(local_m, local_nnz, kp) / passes
     achieved = balg / kavg if kavg > 0 else 0.0
+    vec = min(4, max(1, kp // passes // 64))
+    traffic = pmc_traffic(args.graph, k, passes) if not sharded and args.scale == 1.0 else None
 
     if rank == 0:
         flops = 2.0 * nnz * k
@@ -172,18 +193,25 @@ def main():
                 "chunks": f"{local_adj.num_chunks} x {local_adj.chunk_size} nnz",
             },
             "roofline": {
-                "bound": "hbm", "kernel": "spmm_chunk_kernel<VEC=2,U=8>" if k == 128 else "spmm_chunk_kernel",
+                "bound": "hbm", "kernel": f"gcn::spmm_chunk_kernel<{vec}, {8 if vec < 4 else 4}, false>",
                 "achieved": round(achieved / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK, 4),
                 "frac_of_measured_copy_peak_6.29TBps": round(achieved / 6.29e12, 4),
-                "algorithmic_bytes_per_launch": balg,
-                "kernel_ms_avg": round(kavg * 1e3, 4), "kernel_ms_min": round(min(kernel_ms), 4) if kernel_ms else None,
-                "kernel_launches_timed": len(kernel_ms),
-                "traffic": None,
+                "algorithmic_bytes_per_launch": int(balg),
+                "launches_per_spmm": passes, "columns_per_launch": kp // passes,
+                "kernel_ms_avg": round(kavg * 1e3, 4),
+                "spmm_ms_min": round(min(kernel_ms), 4) if kernel_ms else None,
+                "spmms_timed": len(kernel_ms),
+                "timing": "HIP events recorded by libgcnspmm on the launch stream around the main-kernel "
+                          "passes of every timed SpMM (gcn_spmm_profile_begin/_end)",
+                "traffic": traffic,
+                "traffic_source": None if traffic is None else
+                "profiles/pmc_latest.json (separate rocprofv3 --pmc passes; FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; "
+                "L2-miss bytes incl. Infinity-Cache hits)",
             },
-            "gflops_kernel_only": round(2.0 * local_nnz * k / kavg / 1e9, 1) if kavg > 0 else None,
+            "gflops_kernel_only": round(2.0 * local_nnz * kp / spmm_avg / 1e9, 1) if spmm_avg > 0 else None,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if not sharded and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(rowptr, col, val, n, k, seed=2)
         print(json.dumps(line), flush=True)
 

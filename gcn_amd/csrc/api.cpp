@@ -27,6 +27,14 @@ struct gcn_spmm_plan {
   std::vector<hipEvent_t> ev;   // 2 per recorded launch
   int prof_cap, prof_n;
   int tile_cols;                // 0 = auto
+  // XCD-aware column slicing (slicing.hip): slice-major copy of the matrix with S*m virtual rows
+  int S;                        // 0 = off
+  int* vrowptr;                 // [S*m+1]
+  int* vcol;                    // [nnz]
+  float* vval;                  // [nnz]
+  int* vchunk_row;              // [nchunks] rows of the virtual CSR
+  float* cv;                    // partial outputs [S*m x k], grow-only
+  size_t cv_bytes;
 };
 
 namespace {
@@ -141,6 +149,11 @@ int gcn_spmm_plan_destroy(gcn_spmm_plan_t* p) {
   if (!p) return GCN_OK;
   if (p->chunk_row) (void)hipFree(p->chunk_row);
   if (p->ws) (void)hipFree(p->ws);
+  if (p->vrowptr) (void)hipFree(p->vrowptr);
+  if (p->vcol) (void)hipFree(p->vcol);
+  if (p->vval) (void)hipFree(p->vval);
+  if (p->vchunk_row) (void)hipFree(p->vchunk_row);
+  if (p->cv) (void)hipFree(p->cv);
   for (auto& e : p->ev) (void)hipEventDestroy(e);
   delete p;
   return GCN_OK;
@@ -175,13 +188,82 @@ int gcn_spmm_csr_f32_bias_relu(gcn_spmm_plan_t* p, const int32_t* rowptr, const 
     a.ev_stop = p->ev[2 * p->prof_n + 1];
     ++p->prof_n;
   }
+  if (p->S > 0 && p->nnz > 0) {
+    // sliced: same kernel on the slice-major virtual CSR (S*m rows) into the partial buffer,
+    // then the per-row reduction over slices (which also carries the epilogue)
+    const size_t need = sizeof(float) * (size_t)p->S * (size_t)p->m * (size_t)k;
+    {
+      std::lock_guard<std::mutex> lk(g_mu);
+      if (need > p->cv_bytes) {
+        if (p->cv) (void)hipFree(p->cv);
+        p->cv = nullptr; p->cv_bytes = 0;
+        if (hipMalloc((void**)&p->cv, need) != hipSuccess) return GCN_ERR_ALLOC;
+        p->cv_bytes = need;
+      }
+    }
+    a.rowptr = p->vrowptr; a.col = p->vcol; a.val = p->vval; a.chunk_row = p->vchunk_row;
+    a.C = p->cv; a.m = p->S * p->m; a.bias = nullptr; a.relu = 0;
+    if (gcn::launch_spmm(a, p->cu_count, (hipStream_t)stream) != hipSuccess) return GCN_ERR_HIP;
+    return gcn::launch_slice_reduce(p->cv, C, bias, relu ? 1 : 0, p->m, p->S, k,
+                                    (hipStream_t)stream) == hipSuccess ? GCN_OK : GCN_ERR_HIP;
+  }
   return gcn::launch_spmm(a, p->cu_count, (hipStream_t)stream) == hipSuccess ? GCN_OK : GCN_ERR_HIP;
 }
+
+static void free_slicing(gcn_spmm_plan* p) {
+  if (p->vrowptr) (void)hipFree(p->vrowptr);
+  if (p->vcol) (void)hipFree(p->vcol);
+  if (p->vval) (void)hipFree(p->vval);
+  if (p->vchunk_row) (void)hipFree(p->vchunk_row);
+  if (p->cv) (void)hipFree(p->cv);
+  p->vrowptr = p->vcol = p->vchunk_row = nullptr; p->vval = nullptr; p->cv = nullptr;
+  p->cv_bytes = 0; p->S = 0;
+}
+
+int gcn_spmm_plan_enable_slicing(gcn_spmm_plan_t* p, const int32_t* rowptr, const int32_t* col,
+                                 const float* val, int32_t slices, void* stream) {
+  if (!p || slices < 0 || slices > 1024) return GCN_ERR_INVALID_ARG;
+  free_slicing(p);
+  if (slices <= 1 || p->nnz == 0 || p->m == 0) return GCN_OK;
+  if (!rowptr || !col || !val) return GCN_ERR_INVALID_ARG;
+  if ((long long)slices * p->m + 1 >= (1LL << 31)) return GCN_ERR_INVALID_ARG;
+  const long long vm = (long long)slices * p->m;
+  if (hipMalloc((void**)&p->vrowptr, sizeof(int) * (size_t)(vm + 1)) != hipSuccess ||
+      hipMalloc((void**)&p->vcol, sizeof(int) * (size_t)p->nnz) != hipSuccess ||
+      hipMalloc((void**)&p->vval, sizeof(float) * (size_t)p->nnz) != hipSuccess ||
+      hipMalloc((void**)&p->vchunk_row, sizeof(int) * (size_t)p->nchunks) != hipSuccess) {
+    free_slicing(p);
+    return GCN_ERR_ALLOC;
+  }
+  int sorted = 1;
+  if (gcn::build_sliced_csr(rowptr, col, val, p->m, p->n, p->nnz, slices, p->vrowptr, p->vcol,
+                            p->vval, &sorted, (hipStream_t)stream) != hipSuccess) {
+    free_slicing(p);
+    return GCN_ERR_HIP;
+  }
+  if (!sorted) { free_slicing(p); return GCN_ERR_INVALID_ARG; }   // needs column-sorted rows
+  if (gcn::launch_plan_chunk_rows(p->vrowptr, (int)vm, p->T, p->nchunks, p->vchunk_row,
+                                  (hipStream_t)stream) != hipSuccess) {
+    free_slicing(p);
+    return GCN_ERR_HIP;
+  }
+  p->S = slices;
+  return GCN_OK;
+}
+
+int32_t gcn_spmm_plan_num_slices(const gcn_spmm_plan_t* p) { return p ? p->S : -1; }
 
 int gcn_spmm_plan_set_tile_cols(gcn_spmm_plan_t* p, int32_t cols) {
   if (!p || !(cols == 0 || cols == 64 || cols == 128 || cols == 256)) return GCN_ERR_INVALID_ARG;
   p->tile_cols = cols;
   return GCN_OK;
+}
+
+int32_t gcn_spmm_plan_num_passes(const gcn_spmm_plan_t* p, int32_t k) {
+  if (!p || k <= 0) return -1;
+  const int tile = p->tile_cols ? p->tile_cols : auto_tile_cols(p->n, k);
+  const int vec = gcn::pick_vec(k, tile, nullptr, nullptr, nullptr);   // 16-B aligned operands
+  return (k + 64 * vec - 1) / (64 * vec);
 }
 
 int gcn_spmm_profile_begin(gcn_spmm_plan_t* p, int32_t capacity) {

@@ -1,0 +1,187 @@
+// slicing.hip — XCD-aware column slicing of the adjacency (plan-time) + the reduction that
+// follows a sliced SpMM.
+//
+// Why: on an unordered graph ≈92 % of the feature-row gathers miss the 4 MiB per-XCD L2 and are
+// served by the Infinity Cache, whose random-row bandwidth (≈7.2 TB/s) is what bounds
+// spmm_chunk_kernel (profiles/r01_pmc_*.json).  Slicing cuts the column range [0, n) into S
+// equal slices and reorders the non-zero stream SLICE-MAJOR:
+//
+//     virtual row  R = s·m + r   holds the non-zeros of row r whose column lies in slice s.
+//
+// The SpMM kernel then runs unchanged on this virtual CSR (S·m rows).  Because each XCD walks a
+// CONTIGUOUS range of the chunk stream (spmm_chunk_kernel, XCD-aware ranges), an XCD gathers
+// from only ≈ S/8 slices of B, one after the other — a slice of n/S rows × 256 B (64-column
+// tile) is sized to sit in that XCD's L2.  The kernel writes one partial output row per virtual
+// row (plain stores, each exactly once); slice_reduce_kernel adds the S partials of every real
+// row in slice order (deterministic) and applies the optional bias/ReLU epilogue.
+//
+// Requires columns sorted ascending inside each row (true for the reference's pipeline:
+// renumber.cu:105-117 sorts, torch's to_sparse_csr sorts); rows' slice segments are then
+// contiguous, so the reordering is a segment copy.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+#include <stdint.h>
+#include "spmm_kernels.h"
+
+namespace gcn {
+
+// cnt[s*m + r] = number of non-zeros of row r with column in [s*w, (s+1)*w);  *unsorted is set
+// when a row's columns are not ascending.  One thread per (row, slice boundary).
+__global__ void slice_count_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
+                                   int m, int S, int w, int* __restrict__ split,
+                                   int* __restrict__ unsorted) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long)m * (S + 1)) return;
+  const int r = (int)(t / (S + 1)), s = (int)(t % (S + 1));
+  const int lo0 = rowptr[r], hi0 = rowptr[r + 1];
+  int lo = lo0, hi = hi0;
+  const long long bound = (long long)s * w;
+  while (lo < hi) {                       // first entry with col >= s*w
+    const int mid = (lo + hi) >> 1;
+    if ((long long)col[mid] < bound) lo = mid + 1; else hi = mid;
+  }
+  split[t] = (s == S) ? hi0 : lo;         // the last boundary is the row end (cols < n <= S*w)
+}
+
+__global__ void slice_check_sorted_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
+                                          int m, int* __restrict__ unsorted) {
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int nw = gridDim.x * (blockDim.x >> 6);
+  for (int r = wave; r < m; r += nw)
+    for (int e = rowptr[r] + 1 + lane; e < rowptr[r + 1]; e += 64)
+      if (col[e] < col[e - 1]) *unsorted = 1;
+}
+
+__global__ void slice_sizes_kernel(const int* __restrict__ split, int m, int S, int* __restrict__ cnt) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long)m * S) return;
+  const int s = (int)(t / m), r = (int)(t % m);
+  cnt[t] = split[(long long)r * (S + 1) + s + 1] - split[(long long)r * (S + 1) + s];
+}
+
+// copy every (row, slice) segment to its slice-major position; one wave per row
+__global__ void __launch_bounds__(256)
+slice_scatter_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
+                     const float* __restrict__ val, const int* __restrict__ split,
+                     const int* __restrict__ vrowptr, int m, int S, int w,
+                     int* __restrict__ vcol, float* __restrict__ vval) {
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int nw = gridDim.x * 4;
+  for (int r = wave; r < m; r += nw) {
+    const int beg = rowptr[r], end = rowptr[r + 1];
+    for (int e = beg + lane; e < end; e += 64) {
+      const int c = col[e];
+      const int s = c / w;
+      const int dst = vrowptr[(long long)s * m + r] + (e - split[(long long)r * (S + 1) + s]);
+      vcol[dst] = c;
+      vval[dst] = val[e];
+    }
+  }
+}
+
+// C[r, :] = act( sum_s Cv[s*m + r, :] + bias ), partials added in slice order; wave per row
+template <int VEC>
+__global__ void __launch_bounds__(256)
+slice_reduce_kernel(const float* __restrict__ Cv, float* __restrict__ C,
+                    const float* __restrict__ bias, int relu, int m, int S, int k) {
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int nw = gridDim.x * 4;
+  for (int r = wave; r < m; r += nw) {
+    for (int x = lane * VEC; x < k; x += 64 * VEC) {
+      float acc[VEC];
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+      for (int s = 0; s < S; ++s) {
+        const float* p = Cv + ((size_t)s * m + r) * (size_t)k + x;
+        if (VEC == 4) {
+          const float4 v = *reinterpret_cast<const float4*>(p);
+          acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;
+        } else {
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) acc[i] += p[i];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        if (bias) acc[i] += bias[x + i];
+        if (relu) acc[i] = fmaxf(acc[i], 0.f);
+      }
+      float* o = C + (size_t)r * (size_t)k + x;
+      if (VEC == 4) *reinterpret_cast<float4*>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+      else {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) o[i] = acc[i];
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+#define GCN_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return e_; } while (0)
+
+// Builds the slice-major CSR.  Outputs (device, caller-allocated): vrowptr [S*m+1], vcol/vval
+// [nnz].  `*sorted_out` = 0 if the input rows are not column-sorted (nothing else is valid then).
+hipError_t build_sliced_csr(const int* rowptr, const int* col, const float* val, int m, int n,
+                            int nnz, int S, int* vrowptr, int* vcol, float* vval,
+                            int* sorted_out, hipStream_t st) {
+  *sorted_out = 1;
+  if (m <= 0 || S <= 0) return hipSuccess;
+  const int w = (n + S - 1) / S;          // slice width in columns
+  int *split = nullptr, *cnt = nullptr, *flag = nullptr;
+  void* tmp = nullptr;
+  size_t tmp_bytes = 0;
+  const long long nsplit = (long long)m * (S + 1), ncnt = (long long)m * S;
+  hipError_t err = hipSuccess;
+  auto cleanup = [&]() {
+    if (split) (void)hipFree(split);
+    if (cnt) (void)hipFree(cnt);
+    if (flag) (void)hipFree(flag);
+    if (tmp) (void)hipFree(tmp);
+  };
+#define GCN_GO(x) do { err = (x); if (err != hipSuccess) { cleanup(); return err; } } while (0)
+  GCN_GO(hipMalloc((void**)&split, sizeof(int) * (size_t)nsplit));
+  GCN_GO(hipMalloc((void**)&cnt, sizeof(int) * (size_t)(ncnt + 1)));
+  GCN_GO(hipMalloc((void**)&flag, sizeof(int)));
+  GCN_GO(hipMemsetAsync(flag, 0, sizeof(int), st));
+  slice_check_sorted_kernel<<<2048, 256, 0, st>>>(rowptr, col, m, flag);
+  GCN_GO(hipGetLastError());
+  int unsorted = 0;
+  GCN_GO(hipMemcpyAsync(&unsorted, flag, sizeof(int), hipMemcpyDeviceToHost, st));
+  GCN_GO(hipStreamSynchronize(st));
+  if (unsorted) { *sorted_out = 0; cleanup(); return hipSuccess; }
+  slice_count_kernel<<<(unsigned)((nsplit + 255) / 256), 256, 0, st>>>(rowptr, col, m, S, w, split, flag);
+  GCN_GO(hipGetLastError());
+  slice_sizes_kernel<<<(unsigned)((ncnt + 255) / 256), 256, 0, st>>>(split, m, S, cnt);
+  GCN_GO(hipGetLastError());
+  GCN_GO(hipMemsetAsync(cnt + ncnt, 0, sizeof(int), st));
+  GCN_GO(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, cnt, vrowptr, (int)(ncnt + 1), st));
+  GCN_GO(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
+  GCN_GO(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, cnt, vrowptr, (int)(ncnt + 1), st));
+  int nb = (m + 3) / 4;
+  if (nb > 16384) nb = 16384;
+  slice_scatter_kernel<<<nb, 256, 0, st>>>(rowptr, col, val, split, vrowptr, m, S, w, vcol, vval);
+  GCN_GO(hipGetLastError());
+  GCN_GO(hipStreamSynchronize(st));
+#undef GCN_GO
+  (void)nnz;
+  cleanup();
+  return hipSuccess;
+}
+
+hipError_t launch_slice_reduce(const float* Cv, float* C, const float* bias, int relu, int m, int S,
+                               int k, hipStream_t st) {
+  if (m <= 0 || k <= 0) return hipSuccess;
+  int nb = (m + 3) / 4;
+  if (nb > 8192) nb = 8192;
+  const uintptr_t al = (uintptr_t)Cv | (uintptr_t)C | (uintptr_t)bias;
+  if (k % 4 == 0 && (al & 15) == 0) slice_reduce_kernel<4><<<nb, 256, 0, st>>>(Cv, C, bias, relu, m, S, k);
+  else                              slice_reduce_kernel<1><<<nb, 256, 0, st>>>(Cv, C, bias, relu, m, S, k);
+  return hipGetLastError();
+}
+
+}  // namespace gcn

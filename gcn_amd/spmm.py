@@ -99,6 +99,10 @@ class CsrAdjacency:
         """Feature-column tile per kernel pass (0 auto, 64, 128, 256)."""
         _lib.check(_lib.load().gcn_spmm_plan_set_tile_cols(self.plan, int(cols)), "gcn_spmm_plan_set_tile_cols")
 
+    def num_passes(self, k):
+        """main-kernel launches (column passes) one k-wide SpMM issues"""
+        return int(_lib.load().gcn_spmm_plan_num_passes(self.plan, int(k)))
+
     def profile_begin(self, capacity):
         """Record HIP-event pairs around the main kernel of the next `capacity` launches."""
         _lib.check(_lib.load().gcn_spmm_profile_begin(self.plan, int(capacity)), "gcn_spmm_profile_begin")

@@ -89,6 +89,8 @@ int gcn_spmm_csr_f32_bias_relu(gcn_spmm_plan_t* plan,
  * SpMM runs as ceil(k/tile) back-to-back passes, each gathering only its column slice of B
  * (smaller per-pass working set -> more of it stays in L2 / Infinity Cache). */
 int gcn_spmm_plan_set_tile_cols(gcn_spmm_plan_t* plan, int32_t cols);
+/* number of main-kernel launches (column passes) one k-wide SpMM issues with the current tile */
+int32_t gcn_spmm_plan_num_passes(const gcn_spmm_plan_t* plan, int32_t k);
 
 /* Live kernel timing for bench.py: between _begin and _end every gcn_spmm_csr_f32*
  * call on this plan records a HIP event pair on its launch stream right around the
