@@ -32,6 +32,8 @@ SIGNATURES = {
     "gcn_spmm_csr_f32_bias_relu": (ctypes.c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i32, _c_i32, _c_p]),
     "gcn_spmm_plan_set_tile_cols": (ctypes.c_int, [_c_p, _c_i32]),
     "gcn_spmm_plan_num_passes": (_c_i32, [_c_p, _c_i32]),
+    "gcn_spmm_plan_enable_slicing": (ctypes.c_int, [_c_p, _c_p, _c_p, _c_p, _c_i32, _c_p]),
+    "gcn_spmm_plan_num_slices": (_c_i32, [_c_p]),
     "gcn_spmm_profile_begin": (ctypes.c_int, [_c_p, _c_i32]),
     "gcn_spmm_profile_end": (ctypes.c_int, [_c_p, _c_p, _c_p]),
     "gcn_spmm_csr_f32_oneshot": (ctypes.c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_i32, _c_i32, _c_i32, _c_i32, _c_p]),

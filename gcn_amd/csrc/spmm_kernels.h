@@ -35,4 +35,11 @@ hipError_t launch_gather_rows(float* dst, const float* src, const int* idx, int 
                               hipStream_t s);
 int pick_vec(int k, int tile_cols, const void* B, const void* C, const void* P);
 
+// slicing.hip
+hipError_t build_sliced_csr(const int* rowptr, const int* col, const float* val, int m, int n,
+                            int nnz, int S, int* vrowptr, int* vcol, float* vval,
+                            int* sorted_out, hipStream_t st);
+hipError_t launch_slice_reduce(const float* Cv, float* C, const float* bias, int relu, int m, int S,
+                               int k, hipStream_t st);
+
 }  // namespace gcn

@@ -99,6 +99,17 @@ class CsrAdjacency:
         """Feature-column tile per kernel pass (0 auto, 64, 128, 256)."""
         _lib.check(_lib.load().gcn_spmm_plan_set_tile_cols(self.plan, int(cols)), "gcn_spmm_plan_set_tile_cols")
 
+    def enable_slicing(self, slices):
+        """XCD-aware column slicing (gcn_spmm_plan_enable_slicing); slices <= 1 turns it off."""
+        with torch.cuda.device(self.device):
+            st = _lib.load().gcn_spmm_plan_enable_slicing(self.plan, _ptr(self.rowptr), _ptr(self.col),
+                                                          _ptr(self.val), int(slices), _stream_ptr(self.device))
+        _lib.check(st, "gcn_spmm_plan_enable_slicing")
+
+    @property
+    def num_slices(self):
+        return int(_lib.load().gcn_spmm_plan_num_slices(self.plan))
+
     def num_passes(self, k):
         """main-kernel launches (column passes) one k-wide SpMM issues"""
         return int(_lib.load().gcn_spmm_plan_num_passes(self.plan, int(k)))

@@ -92,6 +92,18 @@ int gcn_spmm_plan_set_tile_cols(gcn_spmm_plan_t* plan, int32_t cols);
 /* number of main-kernel launches (column passes) one k-wide SpMM issues with the current tile */
 int32_t gcn_spmm_plan_num_passes(const gcn_spmm_plan_t* plan, int32_t k);
 
+/* XCD-aware column slicing (optional, off by default).  Builds, on the device, a slice-major copy
+ * of the matrix (`slices` equal column ranges; virtual row s*m+r = the part of row r in slice s)
+ * that later gcn_spmm_csr_f32* calls on this plan use instead of the caller's col/val: every XCD
+ * then gathers from only ~slices/8 column slices of B, sized to stay in its 4 MiB L2, and a
+ * reduction over slices (in slice order, deterministic) produces C.  Needs column-sorted rows
+ * (GCN_ERR_INVALID_ARG otherwise); slices <= 1 turns it off.  The matrix passed here must be the
+ * one the plan was created for.  Costs one extra copy of col/val plus slices*m*k floats. */
+int gcn_spmm_plan_enable_slicing(gcn_spmm_plan_t* plan, const int32_t* rowptr_dev,
+                                 const int32_t* col_dev, const float* val_dev,
+                                 int32_t slices, void* stream);
+int32_t gcn_spmm_plan_num_slices(const gcn_spmm_plan_t* plan);
+
 /* Live kernel timing for bench.py: between _begin and _end every gcn_spmm_csr_f32*
  * call on this plan records a HIP event pair on its launch stream right around the
  * MAIN kernel passes of one SpMM (up to `capacity` SpMM calls).  _end synchronises the events and returns

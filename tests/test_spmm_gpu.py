@@ -322,3 +322,37 @@ def test_row_sharded_blocks_reproduce_the_single_gpu_result_bitwise():
         chain = full.matmul_raw(chain)
     assert rel_err(pipe.result().cpu().numpy(), chain.cpu().numpy()) <= TOL
     assert rel_err(ref.cpu().numpy(), oracle_spmm(rowptr, col, val, H.cpu().numpy())) <= TOL
+
+
+@pytest.mark.parametrize("S,k", [(2, 64), (8, 128), (16, 128), (16, 33), (5, 256), (32, 64)])
+def test_parity_xcd_column_slicing(S, k):
+    """slice-major virtual CSR + reduction over slices (gcn_spmm_plan_enable_slicing), incl. the
+    fused epilogue, empty rows, hub rows and slices that end up empty"""
+    m, n = 3000, 3500
+    rowptr, col, val = random_csr(m, n, 70000, seed=S * 100 + k, empty_rows=0.1, long_rows=[(4, 2500), (9, 1)])
+    rng = np.random.default_rng(S + k)
+    B = rng.standard_normal((n, k)).astype(np.float32)
+    bias = rng.standard_normal(k).astype(np.float32)
+    adj = _adj(rowptr, col, val, m, n, chunk_nnz=128)
+    adj.enable_slicing(S)
+    assert adj.num_slices == S
+    d = _dev()
+    C = adj.matmul_raw(torch.from_numpy(B).to(d)).cpu().numpy()
+    Cref = oracle_spmm(rowptr, col, val, B)
+    assert rel_err(C, Cref) <= TOL
+    C2 = adj.matmul_raw(torch.from_numpy(B).to(d), bias=torch.from_numpy(bias).to(d), relu=True).cpu().numpy()
+    assert rel_err(C2, np.maximum(Cref + bias, 0)) <= TOL
+    assert torch.equal(adj.matmul_raw(torch.from_numpy(B).to(d)), adj.matmul_raw(torch.from_numpy(B).to(d)))
+    adj.enable_slicing(0)                                       # off again → plain path
+    assert adj.num_slices == 0
+    assert rel_err(adj.matmul_raw(torch.from_numpy(B).to(d)).cpu().numpy(), Cref) <= TOL
+
+
+def test_slicing_refuses_unsorted_rows():
+    m = n = 500
+    rowptr, col, val = random_csr(m, n, 5000, seed=1, sorted_cols=False)
+    adj = _adj(rowptr, col, val, m, n)
+    with pytest.raises(gcn_amd.GcnAmdError):
+        adj.enable_slicing(8)
+    B = np.random.default_rng(0).standard_normal((n, 64)).astype(np.float32)   # plain path still fine
+    assert rel_err(adj.matmul_raw(torch.from_numpy(B).to(_dev())).cpu().numpy(), oracle_spmm(rowptr, col, val, B)) <= TOL

@@ -22,19 +22,22 @@ def main():
     ap.add_argument("--chunks", default="0")
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--tiles", default="0")
+    ap.add_argument("--slices", default="0")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     rowptr, col, val, n = graphgen.make_graph(args.graph, device=dev, seed=1, scale=args.scale)
     nnz = int(col.numel())
     deg = (rowptr[1:] - rowptr[:-1])
     print(f"# graph {args.graph} n={n} nnz={nnz} mean_deg={nnz / n:.1f} max_deg={int(deg.max())}", flush=True)
-    print("k tile chunk nchunks kernel_ms(avg) kernel_ms(min) step_ms GFLOP/s algGB/s frac_of_8TBps", flush=True)
+    print("k tile slices chunk nchunks mainkernels_ms(avg) mainkernels_ms(min) spmm_ms GFLOP/s(spmm) algGB/s(spmm) frac_of_8TBps(spmm)", flush=True)
     for k in [int(x) for x in args.ks.split(",")]:
         H = graphgen.random_features(n, k, seed=2, device=dev)
         out = torch.empty((n, k), device=dev)
-        for chunk, tile in [(int(x), int(t)) for x in args.chunks.split(",") for t in args.tiles.split(",")]:
+        for chunk, tile, S in [(int(x), int(t), int(sl)) for x in args.chunks.split(",")
+                               for t in args.tiles.split(",") for sl in args.slices.split(",")]:
             adj = gcn_amd.CsrAdjacency(rowptr, col, val, (n, n), symmetric=True, chunk_nnz=chunk)
             adj.set_tile_cols(tile)
+            adj.enable_slicing(S)
             for _ in range(3):
                 adj.matmul_raw(H, out=out)
             torch.cuda.synchronize()
@@ -49,8 +52,8 @@ def main():
             step = e0.elapsed_time(e1) / args.iters
             avg, mn = sum(ms) / len(ms), min(ms)
             balg = nnz * (8 + 4 * k) + (n + 1) * 4 + n * k * 4
-            print(f"{k} {tile} {adj.chunk_size} {adj.num_chunks} {avg:.4f} {mn:.4f} {step:.4f} "
-                  f"{2.0 * nnz * k / avg / 1e6:.1f} {balg / avg / 1e6:.1f} {balg / avg / 1e-3 / 8e12:.4f}", flush=True)
+            print(f"{k} {tile} {S} {adj.chunk_size} {adj.num_chunks} {avg:.4f} {mn:.4f} {step:.4f} "
+                  f"{2.0 * nnz * k / step / 1e6:.1f} {balg / step / 1e6:.1f} {balg / step / 1e-3 / 8e12:.4f}", flush=True)
             del adj
         del H, out
 
