@@ -180,7 +180,7 @@ int gcn_spmm_csr_f32_bias_relu(gcn_spmm_plan_t* p, const int32_t* rowptr, const 
   gcn::SpmmArgs a;
   a.rowptr = rowptr; a.col = col; a.val = val; a.B = B; a.C = C; a.P = p->ws;
   a.chunk_row = p->chunk_row; a.bias = bias; a.relu = relu ? 1 : 0;
-  a.nchunks = p->nchunks; a.T = p->T; a.m = p->m; a.nnz = p->nnz; a.k = k;
+  a.nchunks = p->nchunks; a.T = p->T; a.m = p->m; a.nnz = p->nnz; a.k = k; a.n = p->n;
   a.nnz_dev = nullptr; a.nchunks_grid = p->nchunks;
   a.tile_cols = p->tile_cols ? p->tile_cols : auto_tile_cols(p->n, k);
   if (p->prof_cap > 0 && p->prof_n < p->prof_cap) {
@@ -328,7 +328,7 @@ int gcn_spmm_csr_f32_oneshot(const int32_t* rowptr, const int32_t* col, const fl
   gcn::SpmmArgs a;
   a.rowptr = rowptr; a.col = col; a.val = val; a.B = B; a.C = C; a.P = p->ws;
   a.chunk_row = p->chunk_row; a.bias = nullptr; a.relu = 0;
-  a.nchunks = p->nchunks; a.T = p->T; a.m = m; a.nnz = nnz; a.k = k;
+  a.nchunks = p->nchunks; a.T = p->T; a.m = m; a.nnz = nnz; a.k = k; a.n = n;
   a.nnz_dev = nullptr; a.nchunks_grid = p->nchunks;
   a.tile_cols = auto_tile_cols(n, k);
   return gcn::launch_spmm(a, cu, (hipStream_t)stream) == hipSuccess ? GCN_OK : GCN_ERR_HIP;
@@ -528,7 +528,7 @@ void flexspmm(int* seg_rowPtr, float* segNzCV, int* segVoMap, int* grouped_tailS
   a.col = reinterpret_cast<const int*>(segNzCV);
   a.val = nullptr;                       // = segNzCV + nnz, resolved on the device
   a.B = B; a.C = C; a.P = scratch.ws; a.chunk_row = segVoMap; a.bias = nullptr; a.relu = 0;
-  a.nchunks = 0; a.T = T; a.m = m; a.nnz = 0; a.k = k;
+  a.nchunks = 0; a.T = T; a.m = m; a.nnz = 0; a.k = k; a.n = n;
   a.nnz_dev = seg_rowPtr + m;            // exact nnz lives in rowPtr[m]
   a.nchunks_grid = nchunks_ub;
   a.tile_cols = auto_tile_cols(n, k);

@@ -17,6 +17,7 @@ struct SpmmArgs {
   const float* bias;       // [k] or nullptr
   int relu;
   int nchunks, T, m, nnz, k;
+  int n = 0x7fffffff;      // rows of B (columns of A); decides 32-bit buffer addressing
   // drop-in mode (flexspmm symbol): nnz is only known on the device (nnz_dev =
   // &rowptr[m]); the kernels then derive nchunks and the value pointer themselves
   // and the host sizes its grids with the upper bound nchunks_grid.

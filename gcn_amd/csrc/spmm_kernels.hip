@@ -55,6 +55,28 @@ __device__ __forceinline__ void store_vec(float* p, const float (&in)[VEC]) {
 
 __device__ __forceinline__ int sgpr(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// One gathered feature-row slice: 64 lanes x VEC floats.  BUF = buffer addressing: the row base
+// goes into the instruction's SGPR offset (col * row_bytes, 32-bit) and the lane part into a
+// constant VGPR offset, so a gather costs v_readlane + s_mul + buffer_load and no 64-bit vector
+// address arithmetic (requires n*k*4 < 4 GiB); otherwise flat 64-bit addressing.
+template <int VEC, bool BUF>
+__device__ __forceinline__ void gather_row(const float* __restrict__ Bl, __amdgpu_buffer_rsrc_t rsrc,
+                                           int voff, int cu, size_t k, unsigned row_bytes,
+                                           float (&out)[VEC]) {
+  if (BUF) {
+    // VEC == 1 only: hipcc 7.2 lowers __builtin_amdgcn_raw_buffer_load_b64/_b128 to a single
+    // dword load (checked in the ISA), so the 2- and 4-float tiles keep flat addressing.
+    static_assert(!BUF || VEC == 1, "buffer addressing is only instantiated for VEC == 1");
+    const unsigned soff = (unsigned)cu * row_bytes;
+    out[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, soff, 0));
+  } else {
+    load_vec<VEC>(Bl + (size_t)cu * k, out);
+  }
+}
+
 // ---------------------------------------------------------------------------
 // plan kernel: chunk_row[c] = the row that contains non-zero c*T, i.e. the r with
 // rowptr[r] <= c*T < rowptr[r+1];  chunk_row[0] = 0 so that chunk 0 also emits
@@ -78,7 +100,7 @@ __global__ void plan_chunk_rows_kernel(const int* __restrict__ rowptr, int m, in
 // ---------------------------------------------------------------------------
 // main kernel
 // ---------------------------------------------------------------------------
-template <int VEC, int U, bool EPI>
+template <int VEC, int U, bool EPI, bool BUF>
 __global__ void __launch_bounds__(256)
 spmm_chunk_kernel(const int* __restrict__ g_rowptr, const int* __restrict__ g_col,
                   const float* __restrict__ g_val, const float* __restrict__ g_B,
@@ -118,6 +140,11 @@ spmm_chunk_kernel(const int* __restrict__ g_rowptr, const int* __restrict__ g_co
   const bool active = fcol < a.k;
   const float* __restrict__ Bl = a.B + (active ? fcol : 0);
   const size_t k = (size_t)a.k;
+  // buffer descriptor over B (wave-uniform inputs only: kernel arguments)
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(g_B), 0, 0xFFFFFFFFu, 0x00020000);
+  const int voff = (active ? fcol : 0) * 4;
+  const unsigned row_bytes = (unsigned)a.k * 4u;
 
   float bias[VEC];
 #pragma unroll
@@ -177,16 +204,29 @@ spmm_chunk_kernel(const int* __restrict__ g_rowptr, const int* __restrict__ g_co
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const int cu = __builtin_amdgcn_readlane(cj, j + u);
-          load_vec<VEC>(Bl + (size_t)cu * k, b[u]);
+          gather_row<VEC, BUF>(Bl, rsrc, voff, cu, k, row_bytes, b[u]);
         }
+        if (row_end - pos >= U || row_end < 0) {
+          // fast path: the current row does not end strictly inside this batch
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const float vu = __builtin_bit_cast(float,
-              __builtin_amdgcn_readlane(__builtin_bit_cast(int, vj), j + u));
+          for (int u = 0; u < U; ++u) {
+            const float vu = __builtin_bit_cast(float,
+                __builtin_amdgcn_readlane(__builtin_bit_cast(int, vj), j + u));
 #pragma unroll
-          for (int i = 0; i < VEC; ++i) acc[i] = fmaf(vu, b[u][i], acc[i]);
-          ++pos;
+            for (int i = 0; i < VEC; ++i) acc[i] = fmaf(vu, b[u][i], acc[i]);
+          }
+          pos += U;
           while (pos == row_end) flush();
+        } else {
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const float vu = __builtin_bit_cast(float,
+                __builtin_amdgcn_readlane(__builtin_bit_cast(int, vj), j + u));
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) acc[i] = fmaf(vu, b[u][i], acc[i]);
+            ++pos;
+            while (pos == row_end) flush();
+          }
         }
       }
       for (; j < cnt; ++j) {               // ragged tail (last chunk of the matrix only)
@@ -194,7 +234,7 @@ spmm_chunk_kernel(const int* __restrict__ g_rowptr, const int* __restrict__ g_co
         const int cu = __builtin_amdgcn_readlane(cj, j);
         const float vu = __builtin_bit_cast(float,
             __builtin_amdgcn_readlane(__builtin_bit_cast(int, vj), j));
-        load_vec<VEC>(Bl + (size_t)cu * k, b1);
+        gather_row<VEC, BUF>(Bl, rsrc, voff, cu, k, row_bytes, b1);
 #pragma unroll
         for (int i = 0; i < VEC; ++i) acc[i] = fmaf(vu, b1[i], acc[i]);
         ++pos;
@@ -301,9 +341,20 @@ static hipError_t launch_main(const SpmmArgs& a, int nblocks, bool epi, hipStrea
   dim3 grid(nblocks), block(256);
 #define GCN_MAIN_ARGS a.rowptr, a.col, a.val, a.B, a.C, a.P, a.chunk_row, a.bias, a.nnz_dev, \
                       a.relu, a.nchunks, a.T, a.m, a.nnz, a.k, t
+  // buffer addressing needs every byte offset into B to fit 32 bits
+  const bool buf = VEC == 1 && (unsigned long long)a.n * (unsigned long long)a.k * 4ull < 0xFFFFFFF0ull;
   for (int t = 0; t < tiles; ++t) {
-    if (epi) spmm_chunk_kernel<VEC, U, true><<<grid, block, 0, s>>>(GCN_MAIN_ARGS);
-    else     spmm_chunk_kernel<VEC, U, false><<<grid, block, 0, s>>>(GCN_MAIN_ARGS);
+    if constexpr (VEC == 1) {
+      if (buf) {
+        if (epi) spmm_chunk_kernel<VEC, U, true, true><<<grid, block, 0, s>>>(GCN_MAIN_ARGS);
+        else     spmm_chunk_kernel<VEC, U, false, true><<<grid, block, 0, s>>>(GCN_MAIN_ARGS);
+        continue;
+      }
+    }
+    {
+      if (epi) spmm_chunk_kernel<VEC, U, true, false><<<grid, block, 0, s>>>(GCN_MAIN_ARGS);
+      else     spmm_chunk_kernel<VEC, U, false, false><<<grid, block, 0, s>>>(GCN_MAIN_ARGS);
+    }
   }
 #undef GCN_MAIN_ARGS
   return hipGetLastError();
