@@ -77,6 +77,25 @@ int auto_tile_cols(long long n, int k) {
   return 0;                                      // widest tile k allows (<= 256 columns)
 }
 
+// Number of column slices for the XCD-aware slicing (slicing.hip), 0 = do not slice.
+// Measured on MI355X (profiles/r01_sweep_slices_*.txt, Reddit-shaped graphs of 58 k .. 932 k
+// vertices, mean degree 493): the best S keeps one slice of the 64-column tile (n/S x 256 B) near
+// 4-8 MiB (the per-XCD L2 is 4 MiB) with at least ~16 non-zeros per virtual row; at mean degree
+// 51 (products-shaped) slicing loses (virtual rows of ~6 non-zeros, 8 partial rows per output row).
+int auto_slices(long long m, long long n, long long nnz) {
+  if (m <= 0 || nnz <= 0) return 0;
+  const long long per_row = nnz / m / 16;           // slices that still leave >= 16 nnz per virtual row
+  int s_deg = 1;
+  while (2LL * s_deg <= per_row) s_deg *= 2;
+  if (s_deg < 8) return 0;
+  const long long want = (n * 256 + (8LL << 20) - 1) / (8LL << 20);
+  int s_tab = 8;
+  while (s_tab < want) s_tab *= 2;
+  int S = s_tab < s_deg ? s_tab : s_deg;
+  if (S > 64) S = 64;
+  return S;
+}
+
 int ensure_ws(gcn_spmm_plan* p, int k) {
   const size_t need = gcn_spmm_plan_workspace_bytes(p, k);
   if (need <= p->ws_bytes) return GCN_OK;
@@ -182,7 +201,7 @@ int gcn_spmm_csr_f32_bias_relu(gcn_spmm_plan_t* p, const int32_t* rowptr, const 
   a.chunk_row = p->chunk_row; a.bias = bias; a.relu = relu ? 1 : 0;
   a.nchunks = p->nchunks; a.T = p->T; a.m = p->m; a.nnz = p->nnz; a.k = k; a.n = p->n;
   a.nnz_dev = nullptr; a.nchunks_grid = p->nchunks;
-  a.tile_cols = p->tile_cols ? p->tile_cols : auto_tile_cols(p->n, k);
+  a.tile_cols = p->tile_cols ? p->tile_cols : (p->S > 0 ? 64 : auto_tile_cols(p->n, k));
   if (p->prof_cap > 0 && p->prof_n < p->prof_cap) {
     a.ev_start = p->ev[2 * p->prof_n];
     a.ev_stop = p->ev[2 * p->prof_n + 1];
@@ -222,8 +241,10 @@ static void free_slicing(gcn_spmm_plan* p) {
 
 int gcn_spmm_plan_enable_slicing(gcn_spmm_plan_t* p, const int32_t* rowptr, const int32_t* col,
                                  const float* val, int32_t slices, void* stream) {
-  if (!p || slices < 0 || slices > 1024) return GCN_ERR_INVALID_ARG;
+  if (!p || slices < -1 || slices > 1024) return GCN_ERR_INVALID_ARG;
   free_slicing(p);
+  const bool autom = slices == -1;
+  if (autom) slices = auto_slices(p->m, p->n, p->nnz);
   if (slices <= 1 || p->nnz == 0 || p->m == 0) return GCN_OK;
   if (!rowptr || !col || !val) return GCN_ERR_INVALID_ARG;
   if ((long long)slices * p->m + 1 >= (1LL << 31)) return GCN_ERR_INVALID_ARG;
@@ -241,7 +262,10 @@ int gcn_spmm_plan_enable_slicing(gcn_spmm_plan_t* p, const int32_t* rowptr, cons
     free_slicing(p);
     return GCN_ERR_HIP;
   }
-  if (!sorted) { free_slicing(p); return GCN_ERR_INVALID_ARG; }   // needs column-sorted rows
+  if (!sorted) {                          // needs column-sorted rows; auto mode just stays unsliced
+    free_slicing(p);
+    return autom ? GCN_OK : GCN_ERR_INVALID_ARG;
+  }
   if (gcn::launch_plan_chunk_rows(p->vrowptr, (int)vm, p->T, p->nchunks, p->vchunk_row,
                                   (hipStream_t)stream) != hipSuccess) {
     free_slicing(p);
@@ -261,7 +285,7 @@ int gcn_spmm_plan_set_tile_cols(gcn_spmm_plan_t* p, int32_t cols) {
 
 int32_t gcn_spmm_plan_num_passes(const gcn_spmm_plan_t* p, int32_t k) {
   if (!p || k <= 0) return -1;
-  const int tile = p->tile_cols ? p->tile_cols : auto_tile_cols(p->n, k);
+  const int tile = p->tile_cols ? p->tile_cols : (p->S > 0 ? 64 : auto_tile_cols(p->n, k));
   const int vec = gcn::pick_vec(k, tile, nullptr, nullptr, nullptr);   // 16-B aligned operands
   return (k + 64 * vec - 1) / (64 * vec);
 }

@@ -33,7 +33,7 @@ class CsrAdjacency:
     SpMM plan.  The layout is the reference's own CSR hand-off (gcn6.py:302-311:
     ``to_sparse_csr()``, crow/col cast to int32)."""
 
-    def __init__(self, rowptr, col, val, shape, symmetric=None, chunk_nnz=0):
+    def __init__(self, rowptr, col, val, shape, symmetric=None, chunk_nnz=0, slices="auto"):
         if not (rowptr.is_cuda and col.is_cuda and val.is_cuda):
             raise _lib.GcnAmdError("CsrAdjacency needs CUDA/HIP tensors (no CPU path in gcn_amd)")
         self.rowptr = rowptr.to(torch.int32).contiguous()
@@ -47,6 +47,7 @@ class CsrAdjacency:
             raise ValueError("nnz must fit int32 (row-partition the matrix first)")
         self.symmetric = symmetric
         self.chunk_nnz = int(chunk_nnz)
+        self.slices = -1 if slices == "auto" else int(slices)    # XCD-aware column slicing
         self._plan = None
         self._transpose = None
         self.device = self.val.device
@@ -85,6 +86,8 @@ class CsrAdjacency:
             _lib.check(st, "gcn_spmm_plan_create")
             self._plan = handle
             weakref.finalize(self, _destroy_plan, handle)
+            if self.slices not in (0, 1):
+                self.enable_slicing(self.slices)
         return self._plan
 
     @property
@@ -100,7 +103,7 @@ class CsrAdjacency:
         _lib.check(_lib.load().gcn_spmm_plan_set_tile_cols(self.plan, int(cols)), "gcn_spmm_plan_set_tile_cols")
 
     def enable_slicing(self, slices):
-        """XCD-aware column slicing (gcn_spmm_plan_enable_slicing); slices <= 1 turns it off."""
+        """XCD-aware column slicing (gcn_spmm_plan_enable_slicing): 0/1 off, -1 automatic."""
         with torch.cuda.device(self.device):
             st = _lib.load().gcn_spmm_plan_enable_slicing(self.plan, _ptr(self.rowptr), _ptr(self.col),
                                                           _ptr(self.val), int(slices), _stream_ptr(self.device))

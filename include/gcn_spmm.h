@@ -97,7 +97,9 @@ int32_t gcn_spmm_plan_num_passes(const gcn_spmm_plan_t* plan, int32_t k);
  * that later gcn_spmm_csr_f32* calls on this plan use instead of the caller's col/val: every XCD
  * then gathers from only ~slices/8 column slices of B, sized to stay in its 4 MiB L2, and a
  * reduction over slices (in slice order, deterministic) produces C.  Needs column-sorted rows
- * (GCN_ERR_INVALID_ARG otherwise); slices <= 1 turns it off.  The matrix passed here must be the
+ * (GCN_ERR_INVALID_ARG otherwise); slices = 0/1 turns it off; slices = -1 picks the count from
+ * (m, n, nnz) — off for low-degree graphs, 8..64 otherwise — and silently stays off for
+ * unsorted rows.  The matrix passed here must be the
  * one the plan was created for.  Costs one extra copy of col/val plus slices*m*k floats. */
 int gcn_spmm_plan_enable_slicing(gcn_spmm_plan_t* plan, const int32_t* rowptr_dev,
                                  const int32_t* col_dev, const float* val_dev,
