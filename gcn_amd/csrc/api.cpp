@@ -6,6 +6,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -489,7 +490,9 @@ void rabbit(int* rowPtr, int* col, float* vals, int* vomp, int m, int n, int nnz
 // after the call gcn6 shrinks seg_rowPtr to 9*n_segs and segVoMap to 8*n_segs
 // ints and copies everything to the device, gcn6.py:353-366):
 //   n_segs[0]      = nnz / 9                      (so 9*n_segs <= nnz capacity)
-//   seg_rowPtr     = rowPtr[0..m]                 (needs m+1 <= 9*n_segs)
+//   seg_rowPtr     = rowPtr[0..m]                 (needs m+1 <= 9*n_segs) — or, when the graph
+//                    qualifies for XCD-aware slicing (dropin_slices), the slice-major virtual
+//                    row pointer [0..S*m] with col/val reordered to match
 //   segVoMap       = chunk_row[0..nchunks)        (needs nchunks <= 8*n_segs)
 //   segNzCV[0..nnz)      = column indices, int32 bit patterns (exact for any n,
 //                          unlike the reference's float(col), tile.cu:67)
@@ -501,10 +504,20 @@ void rabbit(int* rowPtr, int* col, float* vals, int* vomp, int m, int n, int nnz
 // ---------------------------------------------------------------------------
 static int dropin_T(int n_segs) { return auto_chunk_nnz(9LL * n_segs, 256); }
 
+// Column slices used by the drop-in pair — a pure function of what BOTH csr2tile (host) and
+// flexspmm (device pointers only) know: m, n and n_segs.  Slicing is dropped when the virtual
+// row pointer (S*m+1 ints) would not fit into seg_rowPtr after gcn6 shrinks it to 9*n_segs.
+static int dropin_slices(int m, int n, int n_segs) {
+  const int S = auto_slices(m, n, 9LL * n_segs);
+  if (S <= 1) return 0;
+  if ((long long)S * m + 1 > 9LL * n_segs) return 0;
+  return S;
+}
+
 void csr2tile(int* rowPtr, int* colIdx, float* vals, int m, int n, int nnz, int* vo_mp,
               int* segVoMap, int* seg_rowPtr, float* segNzCV, int* grouped_tailSeg, int* next_seg,
               int tm, int* n_segs) {
-  (void)n; (void)vo_mp;
+  (void)vo_mp;
   if (tm != 8) {
     std::fprintf(stderr, "libgcnspmm: csr2tile: tm must be 8 (got %d)\n", tm);
     std::abort();
@@ -518,18 +531,51 @@ void csr2tile(int* rowPtr, int* colIdx, float* vals, int m, int n, int nnz, int*
                          "buffers (m=%d nnz=%d); need nnz >= m+10\n", m, nnz);
     std::abort();
   }
-  std::memcpy(seg_rowPtr, rowPtr, sizeof(int) * (size_t)(m + 1));
-  for (int i = m + 1; i < 9 * ns; ++i) seg_rowPtr[i] = nnz;
-  // chunk_row[c] = row holding non-zero c*T (first row for c = 0)
+  const int S = dropin_slices(m, n, ns);
+  int* cols = reinterpret_cast<int*>(segNzCV);
+  float* vs = segNzCV + nnz;
+  int vm = m;                                   // rows of the CSR that is packed
+  if (S == 0) {
+    std::memcpy(seg_rowPtr, rowPtr, sizeof(int) * (size_t)(m + 1));
+    std::memcpy(cols, colIdx, sizeof(int) * (size_t)nnz);
+    std::memcpy(vs, vals, sizeof(float) * (size_t)nnz);
+  } else {
+    // slice-major virtual CSR (slicing.hip describes the device-side twin): virtual row
+    // s*m + r = the entries of row r with column in [s*w, (s+1)*w), in ascending column order
+    vm = S * m;
+    const int w = (n + S - 1) / S;
+    std::vector<int> cnt((size_t)vm + 1, 0);
+    for (int r = 0; r < m; ++r)
+      for (int e = rowPtr[r]; e < rowPtr[r + 1]; ++e) ++cnt[(size_t)(colIdx[e] / w) * m + r];
+    int run = 0;
+    for (int i = 0; i < vm; ++i) { seg_rowPtr[i] = run; run += cnt[i]; }
+    seg_rowPtr[vm] = run;
+    std::vector<int> fill(seg_rowPtr, seg_rowPtr + vm);
+    std::vector<std::pair<int, float>> row;
+    for (int r = 0; r < m; ++r) {
+      row.clear();
+      for (int e = rowPtr[r]; e < rowPtr[r + 1]; ++e) row.emplace_back(colIdx[e], vals[e]);
+      // the reference's pipeline hands over column-sorted rows (renumber.cu:105-117); sort if not
+      if (!std::is_sorted(row.begin(), row.end(),
+                          [](const auto& x, const auto& y) { return x.first < y.first; }))
+        std::stable_sort(row.begin(), row.end(),
+                         [](const auto& x, const auto& y) { return x.first < y.first; });
+      for (const auto& [c, v] : row) {
+        const int dst = fill[(size_t)(c / w) * m + r]++;
+        cols[dst] = c;
+        vs[dst] = v;
+      }
+    }
+  }
+  for (int i = vm + 1; i < 9 * ns; ++i) seg_rowPtr[i] = nnz;
+  // chunk_row[c] = (virtual) row holding non-zero c*T (first row for c = 0)
   int r = 0;
   for (int c = 0; c < nchunks; ++c) {
     const long long target = (long long)c * T;
-    while (r < m && rowPtr[r + 1] <= target) ++r;
+    while (r < vm && seg_rowPtr[r + 1] <= target) ++r;
     segVoMap[c] = (c == 0) ? 0 : r;
   }
   for (int i = nchunks; i < 8 * ns; ++i) segVoMap[i] = 0;
-  std::memcpy(segNzCV, colIdx, sizeof(int) * (size_t)nnz);
-  std::memcpy(segNzCV + nnz, vals, sizeof(float) * (size_t)nnz);
   for (int i = 0; i < 256; ++i) { grouped_tailSeg[i] = 0; next_seg[i] = 0; }
   n_segs[0] = ns;
 }
@@ -542,22 +588,38 @@ void flexspmm(int* seg_rowPtr, float* segNzCV, int* segVoMap, int* grouped_tailS
   const int cu = cu_count_cached();
   if (cu <= 0) { std::fprintf(stderr, "libgcnspmm: flexspmm: no HIP device\n"); std::abort(); }
   const int T = dropin_T(n_segs);
+  const int S = dropin_slices(m, n, n_segs);
+  const int vm = S > 0 ? S * m : m;
   const long long nnz_ub = 9LL * n_segs + 8;
   const int nchunks_ub = (int)((nnz_ub + T - 1) / T);
   std::lock_guard<std::mutex> lk(g_mu);
   scratch.nchunks = nchunks_ub;
   if (ensure_ws(&scratch, k) != GCN_OK) die("flexspmm workspace", hipErrorOutOfMemory);
+  if (S > 0) {
+    const size_t need = sizeof(float) * (size_t)vm * (size_t)k;
+    if (need > scratch.cv_bytes) {
+      if (scratch.cv) (void)hipFree(scratch.cv);
+      scratch.cv = nullptr; scratch.cv_bytes = 0;
+      if (hipMalloc((void**)&scratch.cv, need) != hipSuccess) die("flexspmm slice buffer", hipErrorOutOfMemory);
+      scratch.cv_bytes = need;
+    }
+  }
   gcn::SpmmArgs a;
   a.rowptr = seg_rowPtr;
   a.col = reinterpret_cast<const int*>(segNzCV);
   a.val = nullptr;                       // = segNzCV + nnz, resolved on the device
-  a.B = B; a.C = C; a.P = scratch.ws; a.chunk_row = segVoMap; a.bias = nullptr; a.relu = 0;
-  a.nchunks = 0; a.T = T; a.m = m; a.nnz = 0; a.k = k; a.n = n;
-  a.nnz_dev = seg_rowPtr + m;            // exact nnz lives in rowPtr[m]
+  a.B = B; a.C = S > 0 ? scratch.cv : C; a.P = scratch.ws; a.chunk_row = segVoMap;
+  a.bias = nullptr; a.relu = 0;
+  a.nchunks = 0; a.T = T; a.m = vm; a.nnz = 0; a.k = k; a.n = n;
+  a.nnz_dev = seg_rowPtr + vm;           // exact nnz lives at the end of the (virtual) row pointer
   a.nchunks_grid = nchunks_ub;
-  a.tile_cols = auto_tile_cols(n, k);
-  const hipError_t e = gcn::launch_spmm(a, cu, (hipStream_t) nullptr);   // legacy default stream
+  a.tile_cols = S > 0 ? 64 : auto_tile_cols(n, k);
+  hipError_t e = gcn::launch_spmm(a, cu, (hipStream_t) nullptr);         // legacy default stream
   if (e != hipSuccess) die("flexspmm launch", e);
+  if (S > 0) {
+    e = gcn::launch_slice_reduce(scratch.cv, C, nullptr, 0, m, S, k, (hipStream_t) nullptr);
+    if (e != hipSuccess) die("flexspmm slice reduction", e);
+  }
 }
 
 // ---------------------------------------------------------------------------

@@ -106,3 +106,40 @@ def test_csr2tile_packing_respects_caller_capacities():
     assert np.array_equal(seg_rowPtr[: n + 1].numpy(), rowptr)
     assert np.array_equal(segNzCV[:nnz].numpy().view(np.int32), col)        # exact int32 columns
     assert np.array_equal(segNzCV[nnz:2 * nnz].numpy(), val)
+
+
+def test_csr2tile_slice_major_packing_is_a_permutation_of_the_matrix():
+    """host-only: for a dense graph csr2tile packs S*m virtual rows (row r's entries split by
+    column slice, slice-major); unpacking them gives back exactly the input matrix"""
+    import scipy.sparse as sp
+    import torch
+    from gcn_amd import dropin
+    from util import sym_norm_graph
+    n = 800
+    rowptr, col, val = sym_norm_graph(n, 90000, seed=2)
+    nnz = len(col)
+    assert nnz // n >= 128
+    rng = np.random.default_rng(0)           # hand the rows over UNSORTED: csr2tile sorts them itself
+    col_u, val_u = col.copy(), val.copy()
+    for r in range(n):
+        p = rng.permutation(rowptr[r + 1] - rowptr[r]) + rowptr[r]
+        col_u[rowptr[r]:rowptr[r + 1]], val_u[rowptr[r]:rowptr[r + 1]] = col[p], val[p]
+    seg_rowPtr, segNzCV, segVoMap, tail, nxt, n_segs = dropin.csr2tile(
+        torch.from_numpy(rowptr.copy()), torch.from_numpy(col_u), torch.from_numpy(val_u), n, n, nnz,
+        torch.arange(n, dtype=torch.int32))
+    S, w = 8, (n + 7) // 8
+    vrp = seg_rowPtr.numpy()[: S * n + 1]
+    assert vrp[0] == 0 and vrp[-1] == nnz and np.all(np.diff(vrp) >= 0)
+    vcol = segNzCV[:nnz].numpy().view(np.int32)
+    vval = segNzCV[nnz:2 * nnz].numpy()
+    rows = np.repeat(np.arange(S * n), np.diff(vrp))
+    assert np.array_equal(vcol // w, rows // n)                       # every entry sits in its slice
+    A = sp.csr_matrix((val, col, rowptr), shape=(n, n))
+    Bm = sp.coo_matrix((vval, (rows % n, vcol)), shape=(n, n)).tocsr()
+    Bm.sort_indices()
+    assert np.array_equal(Bm.indptr, A.indptr) and np.array_equal(Bm.indices, A.indices)
+    assert np.array_equal(Bm.data, A.data)
+    # chunk_row of the virtual CSR: monotone, within range
+    T = 64 if nnz < 256 * 32 * 16 * 128 else 512
+    cr = segVoMap.numpy()
+    assert np.all(np.diff(cr[: (nnz + 511) // 512]) >= 0) and cr.max() < S * n

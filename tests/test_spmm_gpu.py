@@ -356,3 +356,26 @@ def test_slicing_refuses_unsorted_rows():
         adj.enable_slicing(8)
     B = np.random.default_rng(0).standard_normal((n, 64)).astype(np.float32)   # plain path still fine
     assert rel_err(adj.matmul_raw(torch.from_numpy(B).to(_dev())).cpu().numpy(), oracle_spmm(rowptr, col, val, B)) <= TOL
+
+
+def test_dropin_pair_with_xcd_slicing_on_a_dense_graph():
+    """mean degree >= 128: csr2tile packs the slice-major virtual CSR and flexspmm (which only
+    sees device pointers, m, n, k, n_segs) recovers S, the chunk size and nnz by itself"""
+    n = 3000
+    rowptr, col, val = sym_norm_graph(n, 330000, seed=12)
+    nnz = len(col)
+    assert nnz // n >= 128
+    d = _dev()
+    t_rp, t_ci, t_va = torch.from_numpy(rowptr.copy()), torch.from_numpy(col.copy()), torch.from_numpy(val.copy())
+    out = dropin.csr2tile(t_rp, t_ci, t_va, n, n, nnz, torch.arange(n, dtype=torch.int32))
+    seg_rowPtr, segNzCV, segVoMap, tail, nxt, n_segs = out
+    # the packed row pointer is the virtual one: S*m rows, ends at nnz
+    S = 8
+    assert int(seg_rowPtr[S * n]) == nnz and int(seg_rowPtr[n]) < nnz
+    dev = [t.to(d) for t in (seg_rowPtr, segNzCV, segVoMap, tail, nxt)]
+    rng = np.random.default_rng(5)
+    for k in (16, 128, 200):
+        X = rng.standard_normal((n, k)).astype(np.float32)
+        Xd = torch.from_numpy(X).to(d)
+        C = dropin.flexspmm.apply(dev[0], dev[1], dev[2], n, n, int(n_segs[0]), dev[3], dev[4], Xd)
+        assert rel_err(C.cpu().numpy(), oracle_spmm(rowptr, col, val, X)) <= TOL
