@@ -109,6 +109,30 @@ def make_graph(name, device="cpu", seed=1, scale=1.0):
     return rowptr, col, val, n
 
 
+def make_rmat(scale, edge_factor=16, abcd=(0.57, 0.19, 0.19, 0.05), device="cpu", seed=5, relabel=True):
+    """Graph500-style R-MAT: n = 2^scale vertices, edge_factor*n generated directed edges,
+    symmetrised, de-duplicated, self-loops added, normalised (BASELINE config 5: scale 24,
+    edge factor 16, (.57,.19,.19,.05)).  Vertex labels are randomly permuted (as Graph500
+    prescribes) unless relabel=False.  → (rowptr, col, val, n)"""
+    device = torch.device(device)
+    n = 1 << scale
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    keys = torch.empty(0, dtype=torch.int64, device=device)
+    total, batch = edge_factor * n, 1 << 26
+    done = 0
+    while done < total:                         # in batches: 2^28 samples at scale 24
+        cnt = min(batch, total - done)
+        u, v = _rmat_pairs(n, cnt, abcd, gen, device)
+        lo, hi = torch.minimum(u, v), torch.maximum(u, v)
+        ok = lo != hi
+        keys = torch.unique(torch.cat([keys, lo[ok] * n + hi[ok]]))
+        done += cnt
+        del u, v, lo, hi, ok
+    rowptr, col, val = normalized_adjacency(n, keys, relabel_seed=(seed + 1000) if relabel else None)
+    return rowptr, col, val, n
+
+
 def random_features(n, k, seed=2, device="cpu"):
     """B ~ N(0,1) fp32 [n x k] (the reference standard-scales features, profiling_gcn.py:31-35)."""
     gen = torch.Generator(device=torch.device(device))

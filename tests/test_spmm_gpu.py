@@ -379,3 +379,30 @@ def test_dropin_pair_with_xcd_slicing_on_a_dense_graph():
         Xd = torch.from_numpy(X).to(d)
         C = dropin.flexspmm.apply(dev[0], dev[1], dev[2], n, n, int(n_segs[0]), dev[3], dev[4], Xd)
         assert rel_err(C.cpu().numpy(), oracle_spmm(rowptr, col, val, X)) <= TOL
+
+
+def test_full_size_products_shape_rcm_reordered():
+    """BASELINE config 3: products-shaped graph (n = 2 449 029, nnz ≈ 126.2 M), k = 256,
+    RCM-reordered by the build's order_rcm.  Checked through size-independent properties:
+    sampled rows vs the fp64 oracle, and P·Â·Pᵀ·(P·B) = P·(Â·B) against the un-reordered run."""
+    d = _dev()
+    rowptr, col, val, n = graphgen.make_graph("products", device=d, seed=3)
+    nnz, k = int(col.numel()), 256
+    assert n == 2449029 and abs(nnz - 126.2e6) < 0.1e6
+    B = graphgen.random_features(n, k, seed=2, device=d)
+    base = gcn_amd.CsrAdjacency(rowptr, col, val, (n, n), symmetric=True).matmul_raw(B)
+    rp, ci, va = rowptr.cpu().numpy(), col.cpu().numpy(), val.cpu().numpy()
+    rank = gcn_amd.reorder.order_rcm(rp, ci)
+    assert np.array_equal(np.sort(rank), np.arange(n))                      # a permutation
+    rp2, ci2, va2, vomp = gcn_amd.reorder.apply_rank(rp, ci, va, rank)
+    adj = gcn_amd.CsrAdjacency(torch.from_numpy(rp2).to(d), torch.from_numpy(ci2).to(d),
+                               torch.from_numpy(va2).to(d), (n, n), symmetric=True)
+    vomp_d = torch.from_numpy(vomp).to(d)
+    C = adj.matmul_raw(gcn_amd.gather_rows(B, vomp_d))
+    assert float((C - base[vomp_d.long()]).abs().max() / base.abs().max()) <= TOL
+    rows = np.random.default_rng(1).choice(n, 2048, replace=False); rows.sort()
+    seg = [np.arange(rp[r], rp[r + 1]) for r in rows]
+    sub_rp = np.zeros(len(rows) + 1, np.int32); sub_rp[1:] = np.cumsum([len(s) for s in seg])
+    idx = np.concatenate(seg)
+    Cref = oracle_spmm(sub_rp, ci[idx], va[idx], B.cpu().numpy())
+    assert rel_err(base[torch.from_numpy(rows).to(d)].cpu().numpy(), Cref) <= TOL

@@ -34,17 +34,24 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--graph", default="products")
     ap.add_argument("--scale", type=float, default=0.1)
+    ap.add_argument("--rmat-scale", type=int, default=0, help="use a Graph500 R-MAT of 2^S vertices instead of --graph")
     ap.add_argument("--k", type=int, default=256)
     ap.add_argument("--orders", default="none,deg,rcm,gorder,dfs")
     ap.add_argument("--iters", type=int, default=10)
     args = ap.parse_args()
     dev = torch.device("cuda:0")
-    rowptr, col, val, n = graphgen.make_graph(args.graph, device=dev, seed=3, scale=args.scale)
+    if args.rmat_scale:
+        rowptr, col, val, n = graphgen.make_rmat(args.rmat_scale, device=dev, seed=5)
+        args.graph, args.scale = f"rmat{args.rmat_scale}", 1.0
+    else:
+        rowptr, col, val, n = graphgen.make_graph(args.graph, device=dev, seed=3, scale=args.scale)
     nnz, k = int(col.numel()), args.k
     H = graphgen.random_features(n, k, seed=2, device=dev)
     rp, ci, va = rowptr.cpu().numpy(), col.cpu().numpy(), val.cpu().numpy()
     balg = nnz * (8 + 4 * k) + (n + 1) * 4 + n * k * 4
-    print(f"# graph {args.graph} scale={args.scale} n={n} nnz={nnz} k={k}", flush=True)
+    deg = rowptr[1:] - rowptr[:-1]
+    print(f"# graph {args.graph} scale={args.scale} n={n} nnz={nnz} k={k} mean_deg={nnz / n:.1f} "
+          f"max_deg={int(deg.max())}", flush=True)
     print("order reorder_s kernel_ms GFLOP/s algGB/s frac_of_8TBps max_rel_err_vs_unordered", flush=True)
     base = None
     for name in args.orders.split(","):
@@ -73,7 +80,7 @@ def main():
             base, err = out.clone(), 0.0
         else:
             err = float((out - base[vomp_d.long()]).abs().max() / base.abs().max())
-        print(f"{name} {t_re:.2f} {ms:.4f} {2.0 * nnz * k / ms / 1e6:.1f} {balg / ms / 1e6:.1f} "
+        print(f"{name}[S={adj.num_slices}] {t_re:.2f} {ms:.4f} {2.0 * nnz * k / ms / 1e6:.1f} {balg / ms / 1e6:.1f} "
               f"{balg / ms / 1e-3 / 8e12:.4f} {err:.2e}", flush=True)
         del adj, Hp, out
 
