@@ -193,7 +193,9 @@ def main():
                 "chunks": f"{local_adj.num_chunks} x {local_adj.chunk_size} nnz",
             },
             "roofline": {
-                "bound": "hbm", "kernel": f"gcn::spmm_chunk_kernel<{vec}, {8 if vec < 4 else 4}, false>",
+                "bound": "hbm",
+                "kernel": f"gcn::spmm_chunk_kernel<{vec}, {({1: 32, 2: 8}).get(vec, 4)}, false, {'true' if vec == 1 else 'false'}>",
+                "slices": local_adj.num_slices,
                 "achieved": round(achieved / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK, 4),
                 "frac_of_measured_copy_peak_6.29TBps": round(achieved / 6.29e12, 4),

@@ -25,6 +25,7 @@
 // peak equals the fp32 VALU peak on gfx950 and the contraction is a gather.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "spmm_kernels.h"
 
 namespace gcn {
@@ -192,11 +193,16 @@ spmm_chunk_kernel(const int* __restrict__ g_rowptr, const int* __restrict__ g_co
 
     while (pos == row_end) flush();        // leading empty rows (chunk 0 only)
 
+    // (col, val) of the next 64 non-zeros are fetched one block ahead, so the coalesced index
+    // load is never on the critical path of the gathers that depend on it
+    int   cj_nx = 0;
+    float vj_nx = 0.f;
+    if (start + lane < end) { cj_nx = a.col[start + lane]; vj_nx = a.val[start + lane]; }
     for (int base = start; base < end; base += 64) {
       const int cnt = min(64, end - base);
-      int   cj = 0;
-      float vj = 0.f;
-      if (lane < cnt) { cj = a.col[base + lane]; vj = a.val[base + lane]; }
+      const int   cj = cj_nx;
+      const float vj = vj_nx;
+      if (base + 64 + lane < end) { cj_nx = a.col[base + 64 + lane]; vj_nx = a.val[base + 64 + lane]; }
 
       int j = 0;
       for (; j + U <= cnt; j += U) {
@@ -392,7 +398,17 @@ hipError_t launch_spmm(const SpmmArgs& a, int cu_count, hipStream_t s) {
   switch (pick_vec(a.k, a.tile_cols, a.B, a.C, a.P)) {
     case 4:  e = launch_main<4, 4>(a, nblocks, epi, s); break;
     case 2:  e = launch_main<2, 8>(a, nblocks, epi, s); break;
-    default: e = launch_main<1, 8>(a, nblocks, epi, s); break;
+    default: {
+      // gathers in flight per wave for the 64-column tile (development knob GCN_AMD_U1;
+      // measured on the sliced Reddit-shaped case, whole SpMM: U = 4 / 8 / 16 / 32 ->
+      // 5.16 / 4.33 / 4.18 / 4.09 ms; 52 VGPRs at U = 32, still 8 waves per SIMD)
+      static const int u1 = [] { const char* v = getenv("GCN_AMD_U1"); return v ? atoi(v) : 32; }();
+      if (u1 == 16)     e = launch_main<1, 16>(a, nblocks, epi, s);
+      else if (u1 == 8) e = launch_main<1, 8>(a, nblocks, epi, s);
+      else if (u1 == 4) e = launch_main<1, 4>(a, nblocks, epi, s);
+      else              e = launch_main<1, 32>(a, nblocks, epi, s);
+      break;
+    }
   }
   if (e != hipSuccess) return e;
   if (a.ev_stop && (e = hipEventRecord(a.ev_stop, s)) != hipSuccess) return e;
