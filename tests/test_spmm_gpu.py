@@ -406,3 +406,36 @@ def test_full_size_products_shape_rcm_reordered():
     idx = np.concatenate(seg)
     Cref = oracle_spmm(sub_rp, ci[idx], va[idx], B.cpu().numpy())
     assert rel_err(base[torch.from_numpy(rows).to(d)].cpu().numpy(), Cref) <= TOL
+
+
+def test_rccl_collectives_used_by_the_multi_gpu_path_single_rank():
+    """One box has one GPU, so the N>1 exchange cannot run here; this at least drives the exact
+    RCCL calls of gcn_amd/dist.py (in-place all_gather_into_tensor with async_op, barrier,
+    all_reduce MAX) through backend 'nccl' with world_size 1, around a real sharded SpMM."""
+    import socket
+    import torch.distributed as dist
+    from gcn_amd.dist import PipelinedAggregation, RowShardedAdjacency
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    d = _dev()
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=d)
+    try:
+        n, k = 4000, 128
+        rowptr, col, val = sym_norm_graph(n, 60000, seed=14)
+        t = [torch.from_numpy(x).to(d) for x in (rowptr, col, val)]
+        H = torch.from_numpy(np.random.default_rng(2).standard_normal((n, k)).astype(np.float32)).to(d)
+        sh = RowShardedAdjacency(t[0], t[1], t[2], n, 0, 1, lambda rp, ci, va, shape: gcn_amd.CsrAdjacency(rp, ci, va, shape))
+        sh.world = 1
+        buf_in, buf_out = sh.to_padded(H), sh.new_buffer(k, d)
+        slot = buf_out[0: sh.max_rows]
+        sh.local.matmul_raw(buf_in, out=slot[: sh.rows])
+        work = sh._all_gather(buf_out, slot, None, True)          # the in-place async all-gather
+        work.wait()
+        dist.barrier()
+        tmax = torch.tensor([1.5], dtype=torch.float64, device=d)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        torch.cuda.synchronize()
+        assert float(tmax) == 1.5
+        assert rel_err(sh.from_padded(buf_out).cpu().numpy(), oracle_spmm(rowptr, col, val, H.cpu().numpy())) <= TOL
+    finally:
+        dist.destroy_process_group()
