@@ -94,6 +94,9 @@ int auto_slices(long long m, long long n, long long nnz) {
   while (s_tab < want) s_tab *= 2;
   int S = s_tab < s_deg ? s_tab : s_deg;
   if (S > 64) S = 64;
+  // the degree cap can leave slices far larger than any cache (huge n, moderate degree): then the
+  // partial rows cost traffic and buy no hits — stay unsliced
+  if (n * 256 / S > (32LL << 20)) return 0;
   return S;
 }
 

@@ -439,3 +439,28 @@ def test_rccl_collectives_used_by_the_multi_gpu_path_single_rank():
         assert rel_err(sh.from_padded(buf_out).cpu().numpy(), oracle_spmm(rowptr, col, val, H.cpu().numpy())) <= TOL
     finally:
         dist.destroy_process_group()
+
+
+def test_wide_column_space_beyond_2_pow_24_and_4GiB_of_features():
+    """papers100M-like shard shape in miniature: a row block with a column space of 40 M vertices
+    (column ids above 2^24, where the reference's float-encoded columns lose exactness, tile.cu:67)
+    and a feature matrix of 10 GB (> 4 GiB → 64-bit flat addressing path, 64-bit row offsets).
+    Checked on sampled rows against an fp64 gather-sum."""
+    d = _dev()
+    m, n, k, deg = 1_000_000, 40_000_000, 64, 24
+    g = torch.Generator(device=d); g.manual_seed(7)
+    col = torch.randint(0, n, (m * deg,), generator=g, device=d, dtype=torch.int64)
+    col[:deg] = torch.arange(n - deg, n, device=d)                  # make sure the last columns are hit
+    key = torch.sort(torch.arange(m, device=d).repeat_interleave(deg) * n + col).values
+    col = (key % n).to(torch.int32)
+    rowptr = (torch.arange(m + 1, device=d) * deg).to(torch.int32)
+    val = torch.rand(m * deg, generator=g, device=d) - 0.5
+    B = torch.randn((n, k), generator=g, device=d)
+    assert B.numel() * 4 > (1 << 32) and int(col.max()) > (1 << 24)
+    adj = gcn_amd.CsrAdjacency(rowptr, col, val, (m, n))
+    C = adj.matmul_raw(B)
+    rows = torch.from_numpy(np.random.default_rng(3).choice(m, 4096, replace=False)).to(d)
+    idx = (rows[:, None] * deg + torch.arange(deg, device=d)[None, :]).reshape(-1)
+    ref = (val[idx].double()[:, None] * B[col[idx].long()].double()).reshape(len(rows), deg, k).sum(1)
+    err = float((C[rows].double() - ref).abs().max() / ref.abs().max())
+    assert err <= TOL
