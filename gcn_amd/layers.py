@@ -1,0 +1,212 @@
+"""The callers of the aggregation op, mirrored from pygcn/gcn6.py on top of the native API:
+
+* ``GraphConvolution``  — A(XW) layer  (gcn6.py:66-148)
+* ``GraphConvolution2`` — (AX)W layer  (gcn6.py:151-199)
+* ``GCN``               — the 2-layer model with gcn6's four preprocessing steps in ``fit``
+                          (renumber → schedule → to GPU → permute features; gcn6.py:262-410)
+
+Same constructor arguments, parameter initialisation, layer-order rule (A(XW) for layer 2 on
+pubmed/flickr, (AX)W otherwise, gcn6.py:214-218), per-layer ``xw / af / bi`` timers and training
+loop (Adam, nll_loss on the training rows).  Differences are the ones the path forces: the
+adjacency is a ``CsrAdjacency`` handle instead of the nine tile arguments, labels ARE permuted with
+the features (the reference forgets to, SURVEY defect D4), and the bias add (+ ReLU for layer 1)
+can ride in the SpMM epilogue (``fuse_epilogue=True``).
+"""
+import math
+
+import numpy as np
+import scipy.sparse as sp
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.nn.parameter import Parameter
+
+from . import preprocess, reorder, timers
+from .spmm import CsrAdjacency, _SpmmFunction, gather_rows
+
+
+class _FusedSpmmBiasRelu(torch.autograd.Function):
+    """out = relu(Â·X + b) in one kernel; backward through the ReLU mask, Âᵀ and the bias sum."""
+
+    @staticmethod
+    def forward(ctx, adj, x, bias, relu):
+        out = adj.matmul_raw(x, bias=bias, relu=relu)
+        ctx.adj, ctx.relu, ctx.has_bias = adj, relu, bias is not None
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (out,) = ctx.saved_tensors
+        if ctx.relu:
+            g = g * (out > 0)
+        g = g.contiguous()
+        return None, ctx.adj.transpose().matmul_raw(g), (g.sum(0) if ctx.has_bias else None), None
+
+
+class _Layer(nn.Module):
+    def __init__(self, in_features, out_features, with_bias=True, name="dataset", layer="layer0"):
+        super().__init__()
+        self.in_features, self.out_features, self.layer = in_features, out_features, layer
+        self.weight = Parameter(torch.empty(in_features, out_features))
+        if with_bias:
+            self.bias = Parameter(torch.empty(out_features))
+        else:
+            self.register_parameter("bias", None)
+        self.reset_parameters()
+        self.timers = timers.Timers()
+
+    def reset_parameters(self):                    # gcn6.py:86-94
+        stdv = 1.0 / math.sqrt(self.weight.size(1))
+        self.weight.data.uniform_(-stdv, stdv)
+        if self.bias is not None:
+            self.bias.data.uniform_(-stdv, stdv)
+
+    def reset_timing(self):
+        self.timers.reset()
+
+    def __repr__(self):
+        return f"{self.__class__.__name__} ({self.in_features} -> {self.out_features})"
+
+
+class GraphConvolution(_Layer):
+    """A(XW): support = X·W, output = Â·support (+ bias)  — gcn6.py:99-143."""
+
+    def forward(self, input, adj, relu=False, fuse_epilogue=False):
+        with self.timers.hc.xw:
+            support = torch.spmm(input, self.weight) if input.is_sparse else torch.mm(input, self.weight)
+        if fuse_epilogue:
+            with self.timers.hc.af:
+                return _FusedSpmmBiasRelu.apply(adj, support, self.bias, relu)
+        with self.timers.hc.af:
+            output = _SpmmFunction.apply(adj, support)
+        if self.bias is not None:
+            with self.timers.hc.bi:
+                output = output + self.bias
+        return F.relu(output) if relu else output
+
+
+class GraphConvolution2(_Layer):
+    """(AX)W: support = Â·X, output = support·W (+ bias)  — gcn6.py:184-194."""
+
+    def forward(self, input, adj, relu=False, fuse_epilogue=False):
+        with self.timers.hc.af:
+            support = _SpmmFunction.apply(adj, input)
+        with self.timers.hc.xw:
+            output = torch.mm(support, self.weight)
+        if self.bias is not None:
+            with self.timers.hc.bi:
+                output = output + self.bias
+        return F.relu(output) if relu else output
+
+
+class GCN(nn.Module):
+    """2-layer GCN with the gcn6 training flow on the native SpMM (gcn6.py:201-441)."""
+
+    def __init__(self, nfeat, nhid, nclass, dataset="dataset", dropout=0.5, lr=0.01, weight_decay=5e-4,
+                 with_relu=True, with_bias=True, device=None, order="rabbit", fuse_epilogue=False):
+        super().__init__()
+        assert device is not None, "Please specify 'device'!"
+        self.device, self.nfeat, self.hidden_sizes, self.nclass = device, nfeat, [nhid], nclass
+        self.dataname = dataset
+        self.gc1 = GraphConvolution(nfeat, nhid, with_bias=with_bias, name=dataset, layer="layer1")
+        if dataset in ("pubmed", "flickr"):                                      # gcn6.py:214-218
+            self.gc2 = GraphConvolution(nhid, nclass, with_bias=with_bias, name=dataset, layer="layer2")
+        else:
+            self.gc2 = GraphConvolution2(nhid, nclass, with_bias=with_bias, name=dataset, layer="layer2")
+        self.dropout, self.lr = dropout, lr
+        self.weight_decay = weight_decay if with_relu else 0
+        self.with_relu, self.with_bias = with_relu, with_bias
+        self.order = order                    # None | "dfs" | "gorder" | "rabbit"  (gcn6.py:27-30: RBT default)
+        self.fuse_epilogue = fuse_epilogue
+        self.output = None
+        self.adj = self.features = self.labels = self.vo_mp = None
+        self.dur_fwd = timers.Timer()
+
+    def reset_timing(self):
+        self.dur_fwd.reset()
+        for gc in (self.gc1, self.gc2):
+            gc.reset_timing()
+
+    def forward(self, x, adj):
+        with self.dur_fwd:
+            x = self.gc1(x, adj, relu=self.with_relu, fuse_epilogue=self.fuse_epilogue)
+            x = F.dropout(x, self.dropout, training=self.training)
+            x = self.gc2(x, adj)
+            return F.log_softmax(x, dim=1)
+
+    def initialize(self):
+        self.gc1.reset_parameters()
+        self.gc2.reset_parameters()
+
+    def prepare(self, features, adj, labels, normalize=True):
+        """gcn6.fit steps 1-4 (gcn6.py:271-379): normalise, renumber on the host, build the SpMM
+        schedule, move to the GPU, permute features (and labels)."""
+        if sp.issparse(features):
+            features = np.asarray(features.todense())
+        features = torch.as_tensor(np.asarray(features), dtype=torch.float32)
+        adj_norm = preprocess.normalize_adj_tensor(adj) if normalize else preprocess.sparse_mx_to_torch_sparse_tensor(adj)
+        rp, ci, va, vo_mp = preprocess.to_csr_int32(adj_norm)
+        rp, ci, va, vo_mp = rp.numpy(), ci.numpy(), va.numpy(), vo_mp.numpy()
+        if self.order:                                                           # step 1
+            rp, ci, va, vo_mp = getattr(reorder, self.order)(rp, ci, va)
+        dev = torch.device(self.device)
+        n = len(rp) - 1
+        self.adj = CsrAdjacency(torch.from_numpy(rp).to(dev), torch.from_numpy(ci).to(dev),    # steps 2+3
+                                torch.from_numpy(va).to(dev), (n, n), symmetric=True)
+        self.vo_mp = torch.from_numpy(vo_mp).to(dev)
+        self.features = gather_rows(features.to(dev), self.vo_mp)                # step 4
+        self.labels = torch.as_tensor(np.asarray(labels), dtype=torch.int64).to(dev)[self.vo_mp.long()]
+        inv = torch.empty(n, dtype=torch.int64)
+        inv[torch.from_numpy(vo_mp).long()] = torch.arange(n)
+        self._new_index = inv                 # old vertex id -> row in the renumbered graph (gcn6.py:255-260)
+        return self
+
+    def fit(self, features, adj, labels, idx_train, train_iters=200, initialize=True, verbose=False,
+            normalize=True):
+        if initialize:
+            self.initialize()
+        self.prepare(features, adj, labels, normalize)
+        idx = self._new_index[torch.as_tensor(np.asarray(idx_train)).long()].to(self.labels.device)
+        self.train()
+        opt = torch.optim.Adam(self.parameters(), lr=self.lr, weight_decay=self.weight_decay)
+        ti = timers.Timers()
+        losses = []
+        for i in range(train_iters):
+            opt.zero_grad()
+            with ti.h.fwd:
+                output = self.forward(self.features, self.adj)
+            loss = F.nll_loss(output[idx], self.labels[idx])
+            with ti.h.bwd:
+                loss.backward()
+            opt.step()
+            losses.append(float(loss.detach()))
+            if verbose and i % 10 == 0:
+                print(f"Epoch {i:3d}, training loss: {losses[-1]:.6f}  Fwd: {ti.h.fwd.avms():.3f} ms/iter"
+                      f"  Bwd: {ti.h.bwd.avms():.3f} ms/iter")
+                ti.reset()
+        self.output = output
+        return losses
+
+    def timing_report(self):
+        """the per-layer lines gcn6 prints after fit (gcn6.py:401-410)"""
+        lines = [f"Forward time: {self.dur_fwd.s():.4f} s for {self.dur_fwd.n_calls} calls."]
+        for gc in (self.gc1, self.gc2):
+            t = gc.timers
+            lines.append(f"{gc.layer} xw: {t.h.xw.avms():6.4f} ms  cu {t.c.xw.avms():6.4f} ms "
+                         f" af: {t.h.af.avms():7.4f} ms  cu {t.c.af.avms():7.4f} ms "
+                         f" bi: {t.h.bi.avms():7.4f} ms  cu {t.c.bi.avms():7.4f} ms")
+        return "\n".join(lines)
+
+    @torch.no_grad()
+    def predict(self):
+        """log-probabilities in the ORIGINAL vertex order"""
+        self.eval()
+        out = self.forward(self.features, self.adj)
+        return out[self._new_index.to(out.device)]
+
+    def test(self, idx_test, labels):
+        out = self.predict()
+        idx = torch.as_tensor(np.asarray(idx_test)).long().to(out.device)
+        lab = torch.as_tensor(np.asarray(labels), dtype=torch.int64).to(out.device)
+        return preprocess.accuracy(out[idx], lab[idx])
