@@ -106,6 +106,7 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
+        os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")   # collective kernels ahead of compute in the HW queues
         dist.init_process_group("nccl", device_id=dev)          # nccl == RCCL on ROCm
 
     # ---- inputs (same seeds on every rank → identical graph everywhere) -------------------
@@ -128,6 +129,11 @@ def main():
         # column planes of 64: the RCCL all-gather of one plane overlaps the SpMM of the next
         pipe = PipelinedAggregation(shard, k, dev, plane_cols=64)
         pipe.load(H)
+        if world > 1:
+            # 6 of 8 blocks per CU: the persistent SpMM grid leaves 8 wave slots per CU free so that the
+            # RCCL all-gather kernel runs BESIDE the next plane's SpMM instead of queueing behind it
+            # (costs 2 % of SpMM speed on one GPU, profiles/r01_sweep_blocks_per_cu.txt)
+            shard.local.set_blocks_per_cu(6)
         launches_per_step = len(pipe.widths)
 
         def step():                       # layer l+1 consumes the all-gathered output of layer l

@@ -31,6 +31,7 @@ SIGNATURES = {
     "gcn_spmm_csr_f32": (ctypes.c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i32, _c_p]),
     "gcn_spmm_csr_f32_bias_relu": (ctypes.c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i32, _c_i32, _c_p]),
     "gcn_spmm_plan_set_tile_cols": (ctypes.c_int, [_c_p, _c_i32]),
+    "gcn_spmm_plan_set_blocks_per_cu": (ctypes.c_int, [_c_p, _c_i32]),
     "gcn_spmm_plan_num_passes": (_c_i32, [_c_p, _c_i32]),
     "gcn_spmm_plan_enable_slicing": (ctypes.c_int, [_c_p, _c_p, _c_p, _c_p, _c_i32, _c_p]),
     "gcn_spmm_plan_num_slices": (_c_i32, [_c_p]),

@@ -28,6 +28,7 @@ struct gcn_spmm_plan {
   std::vector<hipEvent_t> ev;   // 2 per recorded launch
   int prof_cap, prof_n;
   int tile_cols;                // 0 = auto
+  int blocks_per_cu;            // persistent grid: blocks of 4 waves per CU (default 8 = all 32 wave slots)
   // XCD-aware column slicing (slicing.hip): slice-major copy of the matrix with S*m virtual rows
   int S;                        // 0 = off
   int* vrowptr;                 // [S*m+1]
@@ -154,6 +155,7 @@ int gcn_spmm_plan_create(gcn_spmm_plan_t** out, const int32_t* rowptr_dev, int32
   p->chunk_row = nullptr; p->ws = nullptr; p->ws_bytes = 0; p->cu_count = cu;
   p->prof_cap = p->prof_n = 0;
   p->tile_cols = 0;
+  p->blocks_per_cu = 8;
   (void)hipGetDevice(&p->device);
   if (p->nchunks > 0) {
     if (hipMalloc((void**)&p->chunk_row, sizeof(int) * (size_t)p->nchunks) != hipSuccess) {
@@ -210,6 +212,7 @@ int gcn_spmm_csr_f32_bias_relu(gcn_spmm_plan_t* p, const int32_t* rowptr, const 
   // 2.02 ms at k = 32), so the sliced copy is used for k > 32 only
   const bool sliced = p->S > 0 && p->nnz > 0 && k > 32;
   a.tile_cols = p->tile_cols ? p->tile_cols : (sliced ? 64 : auto_tile_cols(p->n, k));
+  a.blocks_per_cu = p->blocks_per_cu;
   if (p->prof_cap > 0 && p->prof_n < p->prof_cap) {
     a.ev_start = p->ev[2 * p->prof_n];
     a.ev_stop = p->ev[2 * p->prof_n + 1];
@@ -288,6 +291,12 @@ int32_t gcn_spmm_plan_num_slices(const gcn_spmm_plan_t* p) { return p ? p->S : -
 int gcn_spmm_plan_set_tile_cols(gcn_spmm_plan_t* p, int32_t cols) {
   if (!p || !(cols == 0 || cols == 64 || cols == 128 || cols == 256)) return GCN_ERR_INVALID_ARG;
   p->tile_cols = cols;
+  return GCN_OK;
+}
+
+int gcn_spmm_plan_set_blocks_per_cu(gcn_spmm_plan_t* p, int32_t blocks) {
+  if (!p || blocks < 1 || blocks > 8) return GCN_ERR_INVALID_ARG;
+  p->blocks_per_cu = blocks;
   return GCN_OK;
 }
 

@@ -27,6 +27,8 @@ struct SpmmArgs {
   // kernel (not the fix-up) — the live kernel timing bench.py reports (null = off)
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
   int tile_cols = 0;       // feature-column tile per pass: 0 auto, else 64 / 128 / 256
+  int blocks_per_cu = 8;   // persistent-grid size: 256-thread blocks per CU (1..8); < 8 leaves
+                           // wave slots free for a concurrent kernel (the RCCL all-gather)
 };
 
 hipError_t launch_plan_chunk_rows(const int* rowptr, int m, int T, int nchunks,

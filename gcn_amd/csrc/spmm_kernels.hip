@@ -390,7 +390,7 @@ hipError_t launch_spmm(const SpmmArgs& a, int cu_count, hipStream_t s) {
   }
   // persistent grid: up to 8 blocks of 4 waves per CU, multiple of 8 blocks (XCDs)
   int nblocks = (ng + 3) / 4;
-  const int cap = cu_count * 8;
+  const int cap = cu_count * (a.blocks_per_cu > 0 && a.blocks_per_cu < 8 ? a.blocks_per_cu : 8);
   if (nblocks > cap) nblocks = cap;
   nblocks = (nblocks + 7) & ~7;
   hipError_t e;

@@ -102,6 +102,11 @@ class CsrAdjacency:
         """Feature-column tile per kernel pass (0 auto, 64, 128, 256)."""
         _lib.check(_lib.load().gcn_spmm_plan_set_tile_cols(self.plan, int(cols)), "gcn_spmm_plan_set_tile_cols")
 
+    def set_blocks_per_cu(self, blocks):
+        """Persistent-grid size (1..8 blocks of 4 waves per CU); < 8 leaves room for a concurrent kernel."""
+        _lib.check(_lib.load().gcn_spmm_plan_set_blocks_per_cu(self.plan, int(blocks)),
+                   "gcn_spmm_plan_set_blocks_per_cu")
+
     def enable_slicing(self, slices):
         """XCD-aware column slicing (gcn_spmm_plan_enable_slicing): 0/1 off, -1 automatic."""
         with torch.cuda.device(self.device):

@@ -89,6 +89,10 @@ int gcn_spmm_csr_f32_bias_relu(gcn_spmm_plan_t* plan,
  * SpMM runs as ceil(k/tile) back-to-back passes, each gathering only its column slice of B
  * (smaller per-pass working set -> more of it stays in L2 / Infinity Cache). */
 int gcn_spmm_plan_set_tile_cols(gcn_spmm_plan_t* plan, int32_t cols);
+/* Size of the persistent grid: 256-thread blocks per CU, 1..8 (default 8 = all 32 wave slots of a
+ * CU).  A smaller value leaves wave slots free so that a kernel on another stream — the RCCL
+ * all-gather of the multi-GPU path — can run beside the SpMM instead of behind it. */
+int gcn_spmm_plan_set_blocks_per_cu(gcn_spmm_plan_t* plan, int32_t blocks);
 /* number of main-kernel launches (column passes) one k-wide SpMM issues with the current tile */
 int32_t gcn_spmm_plan_num_passes(const gcn_spmm_plan_t* plan, int32_t k);
 

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--tiles", default="0")
     ap.add_argument("--slices", default="0")
+    ap.add_argument("--blocks-per-cu", type=int, default=8)
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     rowptr, col, val, n = graphgen.make_graph(args.graph, device=dev, seed=1, scale=args.scale)
@@ -38,6 +39,7 @@ def main():
             adj = gcn_amd.CsrAdjacency(rowptr, col, val, (n, n), symmetric=True, chunk_nnz=chunk)
             adj.set_tile_cols(tile)
             adj.enable_slicing(S)
+            adj.set_blocks_per_cu(args.blocks_per_cu)
             for _ in range(3):
                 adj.matmul_raw(H, out=out)
             torch.cuda.synchronize()
