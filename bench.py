@@ -91,6 +91,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-shard", action="store_true",
                     help="debug: run the row-sharded pipelined path even with one rank (no collective)")
+    ap.add_argument("--chunk", type=int, default=0, help="debug: chunk size in non-zeros (0 = automatic)")
+    ap.add_argument("--sim-world", type=int, default=0,
+                    help="debug: on ONE GPU, time rank 0's row block of a W-way partition (compute only, "
+                         "no collective) — a rehearsal of the per-rank work at N = W, not a metric")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -114,9 +118,9 @@ def main():
     nnz, k = int(col.numel()), args.k
     H = graphgen.random_features(n, k, seed=2, device=dev)
 
-    sharded = world > 1 or args.force_shard
+    sharded = world > 1 or args.force_shard or args.sim_world > 1
     if not sharded:
-        adj = gcn_amd.CsrAdjacency(rowptr, col, val, (n, n), symmetric=True)
+        adj = gcn_amd.CsrAdjacency(rowptr, col, val, (n, n), symmetric=True, chunk_nnz=args.chunk)
         out = torch.empty((n, k), dtype=torch.float32, device=dev)
 
         def step():
@@ -124,12 +128,15 @@ def main():
         local_adj, local_nnz, local_m = adj, nnz, n
         launches_per_step = 1
     else:
-        shard = RowShardedAdjacency(rowptr, col, val, n, rank, world,
-                                    lambda rp, ci, va, shape: gcn_amd.CsrAdjacency(rp, ci, va, shape))
+        sim = args.sim_world if (world == 1 and args.sim_world > 1) else 0
+        shard = RowShardedAdjacency(rowptr, col, val, n, rank, sim or world,
+                                    lambda rp, ci, va, shape: gcn_amd.CsrAdjacency(rp, ci, va, shape, chunk_nnz=args.chunk))
+        if sim:
+            shard.collective = False
         # column planes of 64: the RCCL all-gather of one plane overlaps the SpMM of the next
         pipe = PipelinedAggregation(shard, k, dev, plane_cols=64)
         pipe.load(H)
-        if world > 1:
+        if world > 1 or sim:
             # 6 of 8 blocks per CU: the persistent SpMM grid leaves 8 wave slots per CU free so that the
             # RCCL all-gather kernel runs BESIDE the next plane's SpMM instead of queueing behind it
             # (costs 2 % of SpMM speed on one GPU, profiles/r01_sweep_blocks_per_cu.txt)

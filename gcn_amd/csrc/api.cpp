@@ -55,15 +55,18 @@ int cu_count_cached() {
   return cached[dev];
 }
 
-// chunk size: multiple of 64, aims at >= 16 chunks per resident wave (8 blocks x 4
-// waves per CU) so that the static XCD-range schedule stays balanced, capped at 512.
+// chunk size: the largest power of two <= nnz / resident waves (8 blocks x 4 waves per CU), within
+// [64, 2048].  Measured (profiles/r01_sweep_chunk_size.txt): every chunk boundary costs a partial
+// row (slab write + fix-up read) and a row-pointer restart, and that outweighs the load imbalance of
+// having only one or two chunks per wave — Reddit-shaped 1 GPU: T = 512 / 1024 / 2048 / 4096 ->
+// 4.12 / 4.03 / 3.94 / 4.04 ms; rank of an 8-way partition: T = 64 / 512 / 2048 / 4096 ->
+// 0.68 / 0.56 / 0.556 / 0.67 ms.
 int auto_chunk_nnz(long long nnz, int cu) {
   if (cu <= 0) cu = 256;
   const long long waves = (long long)cu * 32;
-  long long t = nnz / (waves * 16);
-  t = (t / 64) * 64;
-  if (t < 64) t = 64;
-  if (t > 512) t = 512;
+  const long long per_wave = nnz / waves;
+  long long t = 64;
+  while (t * 2 <= per_wave && t < 2048) t *= 2;
   return (int)t;
 }
 

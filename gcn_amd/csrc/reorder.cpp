@@ -200,9 +200,6 @@ class LazyBuckets {
     return true;
   }
 
-  bool has_index_gap() const { return false; }
-  u64 none() const { return none_; }
-
  private:
   struct Bucket { u64 first, last; };
   u64 none_;

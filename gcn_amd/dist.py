@@ -42,6 +42,7 @@ class RowShardedAdjacency:
     def __init__(self, rowptr, col, val, n, rank, world, make_local, balance="nnz"):
         rowptr_h = rowptr.detach().cpu().numpy().astype(np.int64)
         self.n, self.rank, self.world = int(n), int(rank), int(world)
+        self.collective = True     # False = compute this rank's block only (single-GPU rehearsal of rank r of W)
         self.bounds = partition_rows(rowptr_h, world, balance)
         sizes = np.diff(self.bounds)
         self.max_rows = int(sizes.max())
@@ -94,7 +95,7 @@ class RowShardedAdjacency:
         slot = out_padded[self.rank * self.max_rows: (self.rank + 1) * self.max_rows]
         if self.rows:
             self.local.matmul_raw(H_padded, out=slot[: self.rows])
-        if self.world > 1:
+        if self.world > 1 and self.collective:
             return self._all_gather(out_padded, slot, group, True)
         return None
 
@@ -105,7 +106,7 @@ class RowShardedAdjacency:
         slot = out_padded[self.rank * self.max_rows: (self.rank + 1) * self.max_rows]
         if self.rows:
             self.local.matmul_raw(H_padded, out=slot[: self.rows])
-        if self.world > 1:
+        if self.world > 1 and self.collective:
             try:
                 dist.all_gather_into_tensor(out_padded, slot, group=group)
             except (RuntimeError, NotImplementedError):     # backends without the flat form

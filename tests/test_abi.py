@@ -139,7 +139,7 @@ def test_csr2tile_slice_major_packing_is_a_permutation_of_the_matrix():
     Bm.sort_indices()
     assert np.array_equal(Bm.indptr, A.indptr) and np.array_equal(Bm.indices, A.indices)
     assert np.array_equal(Bm.data, A.data)
-    # chunk_row of the virtual CSR: monotone, within range
-    T = 64 if nnz < 256 * 32 * 16 * 128 else 512
+    # chunk_row of the virtual CSR: monotone over the used prefix, within range
     cr = segVoMap.numpy()
-    assert np.all(np.diff(cr[: (nnz + 511) // 512]) >= 0) and cr.max() < S * n
+    lead = np.trim_zeros(cr, "b")
+    assert len(lead) >= 1 and np.all(np.diff(lead) >= 0) and cr.max() < S * n
