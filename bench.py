@@ -118,6 +118,17 @@ def main():
     nnz, k = int(col.numel()), args.k
     H = graphgen.random_features(n, k, seed=2, device=dev)
 
+    if world > 1:
+        # every rank generated the graph itself (same seeds): make sure they really agree before the
+        # partition is derived from it — a mismatch would desynchronise the all-gather shapes
+        sig = torch.stack([torch.tensor(float(nnz), device=dev, dtype=torch.float64),
+                           rowptr.double().sum(), col.double().sum()])     # integer sums: exact in fp64
+        lo, hi = sig.clone(), sig.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        if not torch.equal(lo, hi):
+            raise RuntimeError(f"rank {rank}: synthetic graph differs between ranks: {sig.tolist()}")
+
     sharded = world > 1 or args.force_shard or args.sim_world > 1
     if not sharded:
         adj = gcn_amd.CsrAdjacency(rowptr, col, val, (n, n), symmetric=True, chunk_nnz=args.chunk)
