@@ -213,7 +213,8 @@ int gcn_spmm_csr_f32_bias_relu(gcn_spmm_plan_t* p, const int32_t* rowptr, const 
   // narrow feature widths (k <= 32, the GCN hidden/class sizes) gather 128 B or less per
   // non-zero: there the extra partial rows cost more than the L2 hits buy (measured 2.12 vs
   // 2.02 ms at k = 32), so the sliced copy is used for k > 32 only
-  const bool sliced = p->S > 0 && p->nnz > 0 && k > 32;
+  static const int slice_min_k = [] { const char* v = std::getenv("GCN_AMD_SLICE_MIN_K"); return v ? std::atoi(v) : 33; }();
+  const bool sliced = p->S > 0 && p->nnz > 0 && k >= slice_min_k;
   a.tile_cols = p->tile_cols ? p->tile_cols : (sliced ? 64 : auto_tile_cols(p->n, k));
   a.blocks_per_cu = p->blocks_per_cu;
   if (p->prof_cap > 0 && p->prof_n < p->prof_cap) {

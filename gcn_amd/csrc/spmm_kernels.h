@@ -38,6 +38,9 @@ hipError_t launch_gather_rows(float* dst, const float* src, const int* idx, int 
                               hipStream_t s);
 int pick_vec(int k, int tile_cols, const void* B, const void* C, const void* P);
 
+// spmm_narrow.hip — k <= 32: several non-zeros per gather instruction
+hipError_t launch_spmm_narrow(const SpmmArgs& a, int nblocks, bool epi, hipStream_t s);
+
 // slicing.hip
 hipError_t build_sliced_csr(const int* rowptr, const int* col, const float* val, int m, int n,
                             int nnz, int S, int* vrowptr, int* vcol, float* vval,

@@ -395,7 +395,12 @@ hipError_t launch_spmm(const SpmmArgs& a, int cu_count, hipStream_t s) {
   nblocks = (nblocks + 7) & ~7;
   hipError_t e;
   if (a.ev_start && (e = hipEventRecord(a.ev_start, s)) != hipSuccess) return e;
-  switch (pick_vec(a.k, a.tile_cols, a.B, a.C, a.P)) {
+  static const bool narrow_on = [] { const char* v = getenv("GCN_AMD_NARROW"); return !v || v[0] != '0'; }();
+  // k <= 16: several non-zeros per gather instruction (spmm_narrow.hip).  k = 17..32 stays on the
+  // wide kernel: measured 1.67 ms (wide, 32 of 64 lanes) vs 2.94 ms (two non-zeros per instruction).
+  if (a.k <= 16 && narrow_on) {
+    e = launch_spmm_narrow(a, nblocks, epi, s);
+  } else switch (pick_vec(a.k, a.tile_cols, a.B, a.C, a.P)) {
     case 4:  e = launch_main<4, 4>(a, nblocks, epi, s); break;
     case 2:  e = launch_main<2, 8>(a, nblocks, epi, s); break;
     default: {

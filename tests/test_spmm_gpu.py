@@ -42,7 +42,7 @@ def _run(rowptr, col, val, m, n, k, seed=0, **kw):
 
 # every feature width the reference's launcher distinguishes (flexspmm.cu:510-541: 8, 16, 32,
 # <32, >32) plus the BASELINE widths 128/256/512 and awkward ones (odd, non-multiple of 64)
-@pytest.mark.parametrize("k", [1, 4, 7, 8, 16, 32, 33, 64, 100, 128, 130, 192, 256, 300, 512])
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 5, 7, 8, 9, 12, 15, 16, 17, 24, 32, 33, 64, 100, 128, 130, 192, 256, 300, 512])
 def test_parity_feature_widths(k):
     m = n = 3000
     rowptr, col, val = random_csr(m, n, 60000, seed=k)
