@@ -91,3 +91,20 @@ def rabbit(rowptr, col, vals):
 def perm_apply(rowptr, col, vals, vomp):
     """renumber.so:perm_apply (renumber.cu:233-318): apply a given vomp[new]=old."""
     return _renumber("perm_apply", rowptr, col, vals, vomp)
+
+
+def order_deg_device(rowptr, col, which="total", desc=True):
+    """order_deg on the GPU: torch tensors in (any device), rank[old]=new out on the
+    same device.  The key (degree, node id) is a strict total order (order_deg.cu:8-13), so the result
+    is bit-identical to the host version whatever the sort algorithm."""
+    import torch
+    n = rowptr.numel() - 1
+    out_deg = (rowptr[1:] - rowptr[:-1]).to(torch.int64)
+    in_deg = torch.bincount(col.to(torch.int64), minlength=n)
+    deg = {"total": out_deg + in_deg, "out": out_deg, "in": in_deg}[which]
+    ids = torch.arange(n, dtype=torch.int64, device=deg.device)
+    key = (deg.max() - deg if desc else deg) * n + ids          # primary: degree, secondary: id ascending
+    order = torch.argsort(key)
+    rank = torch.empty(n, dtype=torch.int64, device=deg.device)
+    rank[order] = ids
+    return rank

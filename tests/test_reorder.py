@@ -134,3 +134,15 @@ def test_gorder_with_isolated_vertices():
         ctypes.CDLL(REF_ORD).ref_complete_gorder(ctypes.c_void_p(rp.ctypes.data), ctypes.c_void_p(ci.ctypes.data),
                                                  n, nnz, 3, ctypes.c_void_p(o.ctypes.data))
         assert np.array_equal(got, o)
+
+
+def test_order_deg_device_variant_equals_host():
+    """the torch (device-capable) degree ordering is bit-identical to the C++ host one"""
+    import torch
+    rp, ci, va = sym_norm_graph(1500, 9000, seed=8)
+    rng = np.random.default_rng(1)
+    ci2 = ci.copy(); ci2[rng.integers(0, len(ci), 500)] = rng.integers(0, 1500, 500)   # make in != out degrees
+    for which in ("total", "out", "in"):
+        for desc in (True, False):
+            got = reorder.order_deg_device(torch.from_numpy(rp), torch.from_numpy(ci2), which, desc).numpy()
+            assert np.array_equal(got, reorder.order_deg(rp, ci2, which, desc)), (which, desc)
