@@ -129,6 +129,7 @@ def main():
         if not torch.equal(lo, hi):
             raise RuntimeError(f"rank {rank}: synthetic graph differs between ranks: {sig.tolist()}")
 
+    shard_check = None
     sharded = world > 1 or args.force_shard or args.sim_world > 1
     if not sharded:
         adj = gcn_amd.CsrAdjacency(rowptr, col, val, (n, n), symmetric=True, chunk_nnz=args.chunk)
@@ -157,6 +158,19 @@ def main():
         def step():                       # layer l+1 consumes the all-gathered output of layer l
             pipe.step()
         local_adj, local_nnz, local_m = shard.local, shard.local_nnz, shard.rows
+        if world > 1:
+            # one untimed layer through the sharded path (row blocks + all-gathers), checked on rank 0
+            # against the same layer on the unpartitioned matrix: the N > 1 result must be the 1-GPU result
+            pipe.step()
+            got = pipe.result()
+            if rank == 0:
+                full = gcn_amd.CsrAdjacency(rowptr, col, val, (n, n), symmetric=True).matmul_raw(H)
+                shard_check = float((got - full).abs().max() / full.abs().max())
+                del full
+                if not shard_check <= 1e-5:
+                    raise RuntimeError(f"sharded layer differs from the single-GPU layer: rel err {shard_check}")
+            del got
+            pipe.load(H)
         del rowptr, col, val
         torch.cuda.empty_cache()
 
@@ -235,6 +249,7 @@ def main():
                 "profiles/pmc_latest.json (separate rocprofv3 --pmc passes; FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; "
                 "L2-miss bytes incl. Infinity-Cache hits)",
             },
+            "sharded_vs_single_gpu_rel_err": shard_check,
             "gflops_kernel_only": round(2.0 * local_nnz * kp / spmm_avg / 1e9, 1) if spmm_avg > 0 else None,
         }
         if not sharded and not args.no_cpu_baseline:
