@@ -238,6 +238,10 @@ def main():
                 "frac": round(achieved / HBM_PEAK, 4),
                 "frac_of_measured_copy_peak_6.29TBps": round(achieved / 6.29e12, 4),
                 "algorithmic_bytes_per_launch": int(balg),
+                # compulsory traffic (each of A, B, C touched once) and the rate it implies
+                "compulsory_bytes_per_spmm": int(local_nnz * 8 + (local_m + 1) * 4 + n * kp * 4 + local_m * kp * 4),
+                "compulsory_GBps": round((local_nnz * 8 + (local_m + 1) * 4 + n * kp * 4 + local_m * kp * 4)
+                                         / spmm_avg / 1e9, 1) if spmm_avg > 0 else None,
                 "launches_per_spmm": passes, "columns_per_launch": kp // passes,
                 "kernel_ms_avg": round(kavg * 1e3, 4),
                 "spmm_ms_min": round(min(kernel_ms), 4) if kernel_ms else None,

@@ -138,3 +138,26 @@ def random_features(n, k, seed=2, device="cpu"):
     gen = torch.Generator(device=torch.device(device))
     gen.manual_seed(seed)
     return torch.randn((n, k), generator=gen, device=device, dtype=torch.float32)
+
+
+def make_sbm(n, block=512, deg_in=200, deg_out=46, device="cpu", seed=7, relabel=True):
+    """Planted-partition graph (communities of `block` vertices; every vertex draws `deg_in` partners
+    inside its community and `deg_out` anywhere), symmetrised, de-duplicated, self-loops added,
+    normalised, labels randomly permuted.  Unlike R-MAT it HAS the community structure the
+    reference's reorderers (Rabbit, Gorder, RCM) are meant to recover.  → (rowptr, col, val, n)"""
+    device = torch.device(device)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    ids = torch.arange(n, dtype=torch.int64, device=device)
+    base = (ids // block) * block
+    size = torch.clamp(torch.full_like(ids, block), max=n - base)
+    u_in = ids.repeat_interleave(deg_in)
+    v_in = base.repeat_interleave(deg_in) + (torch.rand(n * deg_in, generator=gen, device=device)
+                                              * size.repeat_interleave(deg_in)).long()
+    u_out = ids.repeat_interleave(deg_out)
+    v_out = torch.randint(0, n, (n * deg_out,), generator=gen, device=device, dtype=torch.int64)
+    u, v = torch.cat([u_in, u_out]), torch.cat([v_in, v_out])
+    lo, hi = torch.minimum(u, v), torch.maximum(u, v)
+    keys = torch.unique((lo * n + hi)[lo != hi])
+    rowptr, col, val = normalized_adjacency(n, keys, relabel_seed=(seed + 1000) if relabel else None)
+    return rowptr, col, val, n

@@ -35,12 +35,17 @@ def main():
     ap.add_argument("--graph", default="products")
     ap.add_argument("--scale", type=float, default=0.1)
     ap.add_argument("--rmat-scale", type=int, default=0, help="use a Graph500 R-MAT of 2^S vertices instead of --graph")
+    ap.add_argument("--sbm", type=int, default=0, help="use a planted-partition graph of N vertices (communities of 512)")
     ap.add_argument("--k", type=int, default=256)
     ap.add_argument("--orders", default="none,deg,rcm,gorder,dfs")
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--slices", default="auto", help="auto | 0 | S : XCD-aware column slicing")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
-    if args.rmat_scale:
+    if args.sbm:
+        rowptr, col, val, n = graphgen.make_sbm(args.sbm, device=dev, seed=7)
+        args.graph, args.scale = f"sbm{args.sbm}", 1.0
+    elif args.rmat_scale:
         rowptr, col, val, n = graphgen.make_rmat(args.rmat_scale, device=dev, seed=5)
         args.graph, args.scale = f"rmat{args.rmat_scale}", 1.0
     else:
@@ -72,7 +77,8 @@ def main():
             raise SystemExit(f"unknown order {name}")
         t_re = time.time() - t0
         adj = gcn_amd.CsrAdjacency(torch.from_numpy(rp2).to(dev), torch.from_numpy(ci2).to(dev),
-                                   torch.from_numpy(va2).to(dev), (n, n), symmetric=True)
+                                   torch.from_numpy(va2).to(dev), (n, n), symmetric=True,
+                                   slices=args.slices if args.slices == "auto" else int(args.slices))
         vomp_d = torch.from_numpy(vomp).to(dev)
         Hp = gcn_amd.gather_rows(H, vomp_d)           # B[r,:] <- B[vomp[r],:]  (gcn6.py step 4)
         ms, out = timed_spmm(adj, Hp, args.iters)
