@@ -37,6 +37,10 @@ struct gcn_spmm_plan {
   int* vchunk_row;              // [nchunks] rows of the virtual CSR
   float* cv;                    // partial outputs [S*m x k], grow-only
   size_t cv_bytes;
+  // LDS-staged row panels (spmm_panel.hip): rows per panel, 0 = off; measured window coverage
+  int panel_R;
+  int* panel_w0;                // device [ceil(m / panel_R)]: first column of each panel's window
+  double panel_coverage;
 };
 
 namespace {
@@ -182,6 +186,7 @@ int gcn_spmm_plan_destroy(gcn_spmm_plan_t* p) {
   if (p->vval) (void)hipFree(p->vval);
   if (p->vchunk_row) (void)hipFree(p->vchunk_row);
   if (p->cv) (void)hipFree(p->cv);
+  if (p->panel_w0) (void)hipFree(p->panel_w0);
   for (auto& e : p->ev) (void)hipEventDestroy(e);
   delete p;
   return GCN_OK;
@@ -215,6 +220,17 @@ int gcn_spmm_csr_f32_bias_relu(gcn_spmm_plan_t* p, const int32_t* rowptr, const 
   // 2.02 ms at k = 32), so the sliced copy is used for k > 32 only
   static const int slice_min_k = [] { const char* v = std::getenv("GCN_AMD_SLICE_MIN_K"); return v ? std::atoi(v) : 33; }();
   const bool sliced = p->S > 0 && p->nnz > 0 && k >= slice_min_k;
+  if (p->panel_R > 0 && p->nnz > 0 && k > 32) {
+    // near-diagonal matrix: LDS-staged panels; rows are owned by waves, C written directly
+    a.blocks_per_cu = p->blocks_per_cu;
+    if (p->prof_cap > 0 && p->prof_n < p->prof_cap) {
+      a.ev_start = p->ev[2 * p->prof_n];
+      a.ev_stop = p->ev[2 * p->prof_n + 1];
+      ++p->prof_n;
+    }
+    return gcn::launch_spmm_panel(a, p->panel_R, p->panel_w0, (hipStream_t)stream) == hipSuccess
+               ? GCN_OK : GCN_ERR_HIP;
+  }
   a.tile_cols = p->tile_cols ? p->tile_cols : (sliced ? 64 : auto_tile_cols(p->n, k));
   a.blocks_per_cu = p->blocks_per_cu;
   if (p->prof_cap > 0 && p->prof_n < p->prof_cap) {
@@ -292,6 +308,32 @@ int gcn_spmm_plan_enable_slicing(gcn_spmm_plan_t* p, const int32_t* rowptr, cons
 
 int32_t gcn_spmm_plan_num_slices(const gcn_spmm_plan_t* p) { return p ? p->S : -1; }
 
+int gcn_spmm_plan_enable_panels(gcn_spmm_plan_t* p, const int32_t* rowptr, const int32_t* col,
+                                int32_t mode, void* stream) {
+  if (!p || mode < -1 || mode > 1) return GCN_ERR_INVALID_ARG;
+  p->panel_R = 0;
+  p->panel_coverage = 0.0;
+  if (p->panel_w0) { (void)hipFree(p->panel_w0); p->panel_w0 = nullptr; }
+  if (mode == 0 || p->nnz == 0 || p->m == 0) return GCN_OK;
+  if (!rowptr || !col) return GCN_ERR_INVALID_ARG;
+  const int R = 128;
+  const int panels = (p->m + R - 1) / R;
+  if (hipMalloc((void**)&p->panel_w0, sizeof(int) * (size_t)panels) != hipSuccess) return GCN_ERR_ALLOC;
+  unsigned long long inside = 0;
+  if (gcn::panel_plan(rowptr, col, p->m, p->n, R, p->panel_w0, &inside, (hipStream_t)stream) != hipSuccess) {
+    (void)hipFree(p->panel_w0); p->panel_w0 = nullptr;
+    return GCN_ERR_HIP;
+  }
+  p->panel_coverage = (double)inside / (double)p->nnz;
+  // automatic: only when at least half of the non-zeros are served from the staged tile
+  if (mode == 1 || p->panel_coverage >= 0.5) p->panel_R = R;
+  else { (void)hipFree(p->panel_w0); p->panel_w0 = nullptr; }
+  return GCN_OK;
+}
+
+int32_t gcn_spmm_plan_panel_rows(const gcn_spmm_plan_t* p) { return p ? p->panel_R : -1; }
+double gcn_spmm_plan_panel_coverage(const gcn_spmm_plan_t* p) { return p ? p->panel_coverage : -1.0; }
+
 int gcn_spmm_plan_set_tile_cols(gcn_spmm_plan_t* p, int32_t cols) {
   if (!p || !(cols == 0 || cols == 64 || cols == 128 || cols == 256)) return GCN_ERR_INVALID_ARG;
   p->tile_cols = cols;
@@ -306,6 +348,7 @@ int gcn_spmm_plan_set_blocks_per_cu(gcn_spmm_plan_t* p, int32_t blocks) {
 
 int32_t gcn_spmm_plan_num_passes(const gcn_spmm_plan_t* p, int32_t k) {
   if (!p || k <= 0) return -1;
+  if (p->panel_R > 0 && k > 32) return (k + 63) / 64;
   const int tile = p->tile_cols ? p->tile_cols : (p->S > 0 && k > 32 ? 64 : auto_tile_cols(p->n, k));
   const int vec = gcn::pick_vec(k, tile, nullptr, nullptr, nullptr);   // 16-B aligned operands
   return (k + 64 * vec - 1) / (64 * vec);

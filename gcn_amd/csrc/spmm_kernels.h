@@ -41,6 +41,11 @@ int pick_vec(int k, int tile_cols, const void* B, const void* C, const void* P);
 // spmm_narrow.hip — k <= 32: several non-zeros per gather instruction
 hipError_t launch_spmm_narrow(const SpmmArgs& a, int nblocks, bool epi, hipStream_t s);
 
+// spmm_panel.hip — LDS-staged feature tiles per row panel (near-diagonal matrices)
+hipError_t panel_plan(const int* rowptr, const int* col, int m, int n, int R, int* w0_dev,
+                      unsigned long long* inside_host, hipStream_t st);
+hipError_t launch_spmm_panel(const SpmmArgs& a, int R, const int* panel_w0, hipStream_t s);
+
 // slicing.hip
 hipError_t build_sliced_csr(const int* rowptr, const int* col, const float* val, int m, int n,
                             int nnz, int S, int* vrowptr, int* vcol, float* vval,

@@ -33,7 +33,7 @@ class CsrAdjacency:
     SpMM plan.  The layout is the reference's own CSR hand-off (gcn6.py:302-311:
     ``to_sparse_csr()``, crow/col cast to int32)."""
 
-    def __init__(self, rowptr, col, val, shape, symmetric=None, chunk_nnz=0, slices="auto"):
+    def __init__(self, rowptr, col, val, shape, symmetric=None, chunk_nnz=0, slices="auto", panels=0):
         if not (rowptr.is_cuda and col.is_cuda and val.is_cuda):
             raise _lib.GcnAmdError("CsrAdjacency needs CUDA/HIP tensors (no CPU path in gcn_amd)")
         self.rowptr = rowptr.to(torch.int32).contiguous()
@@ -48,6 +48,9 @@ class CsrAdjacency:
         self.symmetric = symmetric
         self.chunk_nnz = int(chunk_nnz)
         self.slices = -1 if slices == "auto" else int(slices)    # XCD-aware column slicing
+        # LDS-staged row panels: off unless asked for ("auto" = by measured window coverage) — on MI355X
+        # the chunk kernel is still faster even on community-ordered graphs
+        self.panels = -1 if panels == "auto" else int(bool(panels))
         self._plan = None
         self._transpose = None
         self.device = self.val.device
@@ -86,7 +89,9 @@ class CsrAdjacency:
             _lib.check(st, "gcn_spmm_plan_create")
             self._plan = handle
             weakref.finalize(self, _destroy_plan, handle)
-            if self.slices not in (0, 1):
+            if self.panels != 0:
+                self.enable_panels(self.panels)
+            if self.slices not in (0, 1) and self.panel_rows == 0:
                 self.enable_slicing(self.slices)
         return self._plan
 
@@ -106,6 +111,21 @@ class CsrAdjacency:
         """Persistent-grid size (1..8 blocks of 4 waves per CU); < 8 leaves room for a concurrent kernel."""
         _lib.check(_lib.load().gcn_spmm_plan_set_blocks_per_cu(self.plan, int(blocks)),
                    "gcn_spmm_plan_set_blocks_per_cu")
+
+    def enable_panels(self, mode):
+        """LDS-staged row panels (gcn_spmm_plan_enable_panels): 0 off, 1 on, -1 automatic."""
+        with torch.cuda.device(self.device):
+            st = _lib.load().gcn_spmm_plan_enable_panels(self.plan, _ptr(self.rowptr), _ptr(self.col),
+                                                         int(mode), _stream_ptr(self.device))
+        _lib.check(st, "gcn_spmm_plan_enable_panels")
+
+    @property
+    def panel_rows(self):
+        return int(_lib.load().gcn_spmm_plan_panel_rows(self.plan))
+
+    @property
+    def panel_coverage(self):
+        return float(_lib.load().gcn_spmm_plan_panel_coverage(self.plan))
 
     def enable_slicing(self, slices):
         """XCD-aware column slicing (gcn_spmm_plan_enable_slicing): 0/1 off, -1 automatic."""

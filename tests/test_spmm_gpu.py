@@ -464,3 +464,53 @@ def test_wide_column_space_beyond_2_pow_24_and_4GiB_of_features():
     ref = (val[idx].double()[:, None] * B[col[idx].long()].double()).reshape(len(rows), deg, k).sum(1)
     err = float((C[rows].double() - ref).abs().max() / ref.abs().max())
     assert err <= TOL
+
+
+def _banded_csr(n, half_band, extra, seed, hub=None):
+    """near-diagonal matrix (what a renumbered community graph looks like) + a few far entries"""
+    rng = np.random.default_rng(seed)
+    rows, cols = [], []
+    for r in range(n):
+        lo, hi = max(0, r - half_band), min(n, r + half_band + 1)
+        c = rng.choice(np.arange(lo, hi), size=min(hi - lo, int(rng.integers(0, 2 * half_band // 3 + 2))), replace=False)
+        far = rng.integers(0, n, extra)
+        cc = np.unique(np.concatenate([c, far]))
+        if hub is not None and r == hub[0]:
+            cc = np.unique(rng.choice(n, hub[1], replace=False))
+        rows.append(np.full(len(cc), r)); cols.append(cc)
+    rows, cols = np.concatenate(rows), np.concatenate(cols)
+    import scipy.sparse as sp
+    A = sp.csr_matrix((rng.standard_normal(len(rows)).astype(np.float32), (rows, cols)), shape=(n, n))
+    A.sort_indices()
+    return A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.astype(np.float32)
+
+
+@pytest.mark.parametrize("k", [33, 64, 100, 128, 200])
+def test_parity_lds_staged_row_panels(k):
+    """spmm_panel_kernel: window hits from LDS, misses from global, hub row by the whole workgroup,
+    empty rows, last partial panel, epilogue; forced on and automatic"""
+    n = 3001
+    rowptr, col, val = _banded_csr(n, 150, 3, seed=k, hub=(777, 2600))
+    rng = np.random.default_rng(k)
+    B = rng.standard_normal((n, k)).astype(np.float32)
+    bias = rng.standard_normal(k).astype(np.float32)
+    d = _dev()
+    adj = _adj(rowptr, col, val, n, n, panels=1)
+    assert adj.panel_rows > 0 and adj.panel_coverage > 0.8
+    Cref = oracle_spmm(rowptr, col, val, B)
+    assert rel_err(adj.matmul_raw(torch.from_numpy(B).to(d)).cpu().numpy(), Cref) <= TOL
+    C2 = adj.matmul_raw(torch.from_numpy(B).to(d), bias=torch.from_numpy(bias).to(d), relu=True).cpu().numpy()
+    assert rel_err(C2, np.maximum(Cref + bias, 0)) <= TOL
+    auto = _adj(rowptr, col, val, n, n, panels="auto")       # by coverage: >= 0.5 → panels on
+    assert auto.panel_rows > 0 and auto.num_slices == 0
+    assert torch.equal(auto.matmul_raw(torch.from_numpy(B).to(d)), adj.matmul_raw(torch.from_numpy(B).to(d)))
+
+
+def test_panels_stay_off_for_unstructured_graphs_and_work_when_forced():
+    m, n, k = 2500, 3000, 128
+    rowptr, col, val = random_csr(m, n, 60000, seed=5, empty_rows=0.1, long_rows=[(9, 2500)])
+    auto = _adj(rowptr, col, val, m, n, panels="auto")
+    assert auto.panel_rows == 0 and auto.panel_coverage < 0.5
+    forced = _adj(rowptr, col, val, m, n, panels=1)           # non-square, coverage ~ 17 %: still exact
+    B = np.random.default_rng(0).standard_normal((n, k)).astype(np.float32)
+    assert rel_err(forced.matmul_raw(torch.from_numpy(B).to(_dev())).cpu().numpy(), oracle_spmm(rowptr, col, val, B)) <= TOL

@@ -35,16 +35,17 @@ def _case(seed):
     chunk = int(rng.choice([0, 64, 128, 256]))
     slices = int(rng.choice([0, 0, 2, 3, 8]))
     epi = bool(rng.integers(0, 2))
-    return m, n, rowptr, col, val, k, chunk, slices, epi, rng
+    panels = int(rng.choice([0, 0, 0, 1]))
+    return m, n, rowptr, col, val, k, chunk, slices, epi, panels, rng
 
 
 @pytest.mark.parametrize("seed", range(80))
 def test_random_shape(seed):
-    m, n, rowptr, col, val, k, chunk, slices, epi, rng = _case(seed)
+    m, n, rowptr, col, val, k, chunk, slices, epi, panels, rng = _case(seed)
     d = torch.device("cuda:0")
     B = rng.standard_normal((n, k)).astype(np.float32)
     adj = gcn_amd.CsrAdjacency(torch.from_numpy(rowptr).to(d), torch.from_numpy(col).to(d),
-                               torch.from_numpy(val).to(d), (m, n), chunk_nnz=chunk, slices=slices)
+                               torch.from_numpy(val).to(d), (m, n), chunk_nnz=chunk, slices=slices, panels=panels)
     ref = oracle_spmm(rowptr, col, val, B)
     if epi:
         bias = rng.standard_normal(k).astype(np.float32)
@@ -53,4 +54,4 @@ def test_random_shape(seed):
     else:
         C = adj.matmul_raw(torch.from_numpy(B).to(d)).cpu().numpy()
     assert C.shape == ref.shape
-    assert rel_err(C, ref) <= TOL, (seed, m, n, k, chunk, slices, epi)
+    assert rel_err(C, ref) <= TOL, (seed, m, n, k, chunk, slices, epi, panels)

@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--orders", default="none,deg,rcm,gorder,dfs")
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--slices", default="auto", help="auto | 0 | S : XCD-aware column slicing")
+    ap.add_argument("--panels", default="auto", help="auto | 0 | 1 : LDS-staged row panels")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     if args.sbm:
@@ -78,7 +79,8 @@ def main():
         t_re = time.time() - t0
         adj = gcn_amd.CsrAdjacency(torch.from_numpy(rp2).to(dev), torch.from_numpy(ci2).to(dev),
                                    torch.from_numpy(va2).to(dev), (n, n), symmetric=True,
-                                   slices=args.slices if args.slices == "auto" else int(args.slices))
+                                   slices=args.slices if args.slices == "auto" else int(args.slices),
+                                   panels=args.panels if args.panels == "auto" else int(args.panels))
         vomp_d = torch.from_numpy(vomp).to(dev)
         Hp = gcn_amd.gather_rows(H, vomp_d)           # B[r,:] <- B[vomp[r],:]  (gcn6.py step 4)
         ms, out = timed_spmm(adj, Hp, args.iters)
@@ -86,7 +88,7 @@ def main():
             base, err = out.clone(), 0.0
         else:
             err = float((out - base[vomp_d.long()]).abs().max() / base.abs().max())
-        print(f"{name}[S={adj.num_slices}] {t_re:.2f} {ms:.4f} {2.0 * nnz * k / ms / 1e6:.1f} {balg / ms / 1e6:.1f} "
+        print(f"{name}[S={adj.num_slices},panelR={adj.panel_rows},cov={adj.panel_coverage:.2f}] {t_re:.2f} {ms:.4f} {2.0 * nnz * k / ms / 1e6:.1f} {balg / ms / 1e6:.1f} "
               f"{balg / ms / 1e-3 / 8e12:.4f} {err:.2e}", flush=True)
         del adj, Hp, out
 
