@@ -41,6 +41,13 @@ struct gcn_spmm_plan {
   int panel_R;
   int* panel_w0;                // device [ceil(m / panel_R)]: first column of each panel's window
   double panel_coverage;
+  // A = A_in + A_out: staged entries (LDS byte offsets) / the rest (plain CSR + its chunk plan)
+  int *pin_rowptr, *pin_off;    // [m+1], [nnz_in]
+  float* pin_val;
+  int *pout_rowptr, *pout_col;  // [m+1], [nnz_out]
+  float* pout_val;
+  int* pout_chunk_row;
+  int pout_nnz, pout_T, pout_nchunks;
 };
 
 namespace {
@@ -186,7 +193,11 @@ int gcn_spmm_plan_destroy(gcn_spmm_plan_t* p) {
   if (p->vval) (void)hipFree(p->vval);
   if (p->vchunk_row) (void)hipFree(p->vchunk_row);
   if (p->cv) (void)hipFree(p->cv);
-  if (p->panel_w0) (void)hipFree(p->panel_w0);
+  {
+    void* ptrs[] = {p->panel_w0, p->pin_rowptr, p->pin_off, p->pin_val, p->pout_rowptr, p->pout_col,
+                    p->pout_val, p->pout_chunk_row};
+    for (void* q : ptrs) if (q) (void)hipFree(q);
+  }
   for (auto& e : p->ev) (void)hipEventDestroy(e);
   delete p;
   return GCN_OK;
@@ -196,7 +207,8 @@ int32_t gcn_spmm_plan_num_chunks(const gcn_spmm_plan_t* p) { return p ? p->nchun
 int32_t gcn_spmm_plan_chunk_nnz(const gcn_spmm_plan_t* p) { return p ? p->T : -1; }
 size_t gcn_spmm_plan_workspace_bytes(const gcn_spmm_plan_t* p, int32_t k) {
   if (!p || k <= 0) return 0;
-  return sizeof(float) * 2 * (size_t)(p->nchunks > 0 ? p->nchunks : 1) * (size_t)k;
+  int chunks = p->nchunks > p->pout_nchunks ? p->nchunks : p->pout_nchunks;
+  return sizeof(float) * 2 * (size_t)(chunks > 0 ? chunks : 1) * (size_t)k;
 }
 
 int gcn_spmm_csr_f32_bias_relu(gcn_spmm_plan_t* p, const int32_t* rowptr, const int32_t* col,
@@ -221,15 +233,32 @@ int gcn_spmm_csr_f32_bias_relu(gcn_spmm_plan_t* p, const int32_t* rowptr, const 
   static const int slice_min_k = [] { const char* v = std::getenv("GCN_AMD_SLICE_MIN_K"); return v ? std::atoi(v) : 33; }();
   const bool sliced = p->S > 0 && p->nnz > 0 && k >= slice_min_k;
   if (p->panel_R > 0 && p->nnz > 0 && k > 32) {
-    // near-diagonal matrix: LDS-staged panels; rows are owned by waves, C written directly
-    a.blocks_per_cu = p->blocks_per_cu;
+    // A = A_in + A_out: the staged part from LDS (raw sums into C), then the rest accumulated by the
+    // chunk kernel, which also carries the epilogue
+    hipStream_t st = (hipStream_t)stream;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (p->prof_cap > 0 && p->prof_n < p->prof_cap) {
-      a.ev_start = p->ev[2 * p->prof_n];
-      a.ev_stop = p->ev[2 * p->prof_n + 1];
+      ev0 = p->ev[2 * p->prof_n];
+      ev1 = p->ev[2 * p->prof_n + 1];
       ++p->prof_n;
     }
-    return gcn::launch_spmm_panel(a, p->panel_R, p->panel_w0, (hipStream_t)stream) == hipSuccess
-               ? GCN_OK : GCN_ERR_HIP;
+    if (ev0 && hipEventRecord(ev0, st) != hipSuccess) return GCN_ERR_HIP;
+    const int tiles = (k + 63) / 64;
+    for (int t = 0; t < tiles; ++t)
+      if (gcn::launch_panel_in(p->pin_rowptr, p->pin_off, p->pin_val, B, C, p->panel_w0, p->m, p->n, k,
+                               p->panel_R, t, st) != hipSuccess) return GCN_ERR_HIP;
+    if (p->pout_nnz == 0) {
+      if (gcn::launch_panel_epilogue(C, bias, relu ? 1 : 0, p->m, k, st) != hipSuccess) return GCN_ERR_HIP;
+      if (ev1 && hipEventRecord(ev1, st) != hipSuccess) return GCN_ERR_HIP;
+      return GCN_OK;
+    }
+    a.rowptr = p->pout_rowptr; a.col = p->pout_col; a.val = p->pout_val;
+    a.chunk_row = p->pout_chunk_row; a.nchunks = p->pout_nchunks; a.nchunks_grid = p->pout_nchunks;
+    a.T = p->pout_T; a.nnz = p->pout_nnz; a.accumulate = 1;
+    a.tile_cols = p->tile_cols ? p->tile_cols : auto_tile_cols(p->n, k);
+    a.blocks_per_cu = p->blocks_per_cu;
+    a.ev_start = nullptr; a.ev_stop = ev1;
+    return gcn::launch_spmm(a, p->cu_count, st) == hipSuccess ? GCN_OK : GCN_ERR_HIP;
   }
   a.tile_cols = p->tile_cols ? p->tile_cols : (sliced ? 64 : auto_tile_cols(p->n, k));
   a.blocks_per_cu = p->blocks_per_cu;
@@ -308,14 +337,22 @@ int gcn_spmm_plan_enable_slicing(gcn_spmm_plan_t* p, const int32_t* rowptr, cons
 
 int32_t gcn_spmm_plan_num_slices(const gcn_spmm_plan_t* p) { return p ? p->S : -1; }
 
+static void free_panels(gcn_spmm_plan* p) {
+  void* ptrs[] = {p->panel_w0, p->pin_rowptr, p->pin_off, p->pin_val, p->pout_rowptr, p->pout_col,
+                  p->pout_val, p->pout_chunk_row};
+  for (void* q : ptrs) if (q) (void)hipFree(q);
+  p->panel_w0 = p->pin_rowptr = p->pin_off = p->pout_rowptr = p->pout_col = p->pout_chunk_row = nullptr;
+  p->pin_val = p->pout_val = nullptr;
+  p->panel_R = 0; p->pout_nnz = p->pout_T = p->pout_nchunks = 0;
+}
+
 int gcn_spmm_plan_enable_panels(gcn_spmm_plan_t* p, const int32_t* rowptr, const int32_t* col,
-                                int32_t mode, void* stream) {
+                                const float* val, int32_t mode, void* stream) {
   if (!p || mode < -1 || mode > 1) return GCN_ERR_INVALID_ARG;
-  p->panel_R = 0;
+  free_panels(p);
   p->panel_coverage = 0.0;
-  if (p->panel_w0) { (void)hipFree(p->panel_w0); p->panel_w0 = nullptr; }
   if (mode == 0 || p->nnz == 0 || p->m == 0) return GCN_OK;
-  if (!rowptr || !col) return GCN_ERR_INVALID_ARG;
+  if (!rowptr || !col || !val) return GCN_ERR_INVALID_ARG;
   const int R = 128;
   const int panels = (p->m + R - 1) / R;
   if (hipMalloc((void**)&p->panel_w0, sizeof(int) * (size_t)panels) != hipSuccess) return GCN_ERR_ALLOC;
@@ -326,8 +363,37 @@ int gcn_spmm_plan_enable_panels(gcn_spmm_plan_t* p, const int32_t* rowptr, const
   }
   p->panel_coverage = (double)inside / (double)p->nnz;
   // automatic: only when at least half of the non-zeros are served from the staged tile
-  if (mode == 1 || p->panel_coverage >= 0.5) p->panel_R = R;
-  else { (void)hipFree(p->panel_w0); p->panel_w0 = nullptr; }
+  if (!(mode == 1 || p->panel_coverage >= 0.5)) { free_panels(p); return GCN_OK; }
+  // split A = A_in + A_out on the device
+  hipStream_t st = (hipStream_t)stream;
+  const size_t rp_bytes = sizeof(int) * (size_t)(p->m + 1);
+  if (hipMalloc((void**)&p->pin_rowptr, rp_bytes) != hipSuccess ||
+      hipMalloc((void**)&p->pout_rowptr, rp_bytes) != hipSuccess) { free_panels(p); return GCN_ERR_ALLOC; }
+  int nnz_in = 0;
+  if (gcn::panel_split(rowptr, col, val, p->panel_w0, p->m, R, p->pin_rowptr, p->pout_rowptr, nullptr,
+                       nullptr, nullptr, nullptr, &nnz_in, st) != hipSuccess) { free_panels(p); return GCN_ERR_HIP; }
+  const int nnz_out = p->nnz - nnz_in;
+  if (hipMalloc((void**)&p->pin_off, sizeof(int) * (size_t)(nnz_in > 0 ? nnz_in : 1)) != hipSuccess ||
+      hipMalloc((void**)&p->pin_val, sizeof(float) * (size_t)(nnz_in > 0 ? nnz_in : 1)) != hipSuccess ||
+      hipMalloc((void**)&p->pout_col, sizeof(int) * (size_t)(nnz_out > 0 ? nnz_out : 1)) != hipSuccess ||
+      hipMalloc((void**)&p->pout_val, sizeof(float) * (size_t)(nnz_out > 0 ? nnz_out : 1)) != hipSuccess) {
+    free_panels(p); return GCN_ERR_ALLOC;
+  }
+  if (gcn::panel_split(rowptr, col, val, p->panel_w0, p->m, R, p->pin_rowptr, p->pout_rowptr, p->pin_off,
+                       p->pin_val, p->pout_col, p->pout_val, &nnz_in, st) != hipSuccess) {
+    free_panels(p); return GCN_ERR_HIP;
+  }
+  p->pout_nnz = nnz_out;
+  p->pout_T = auto_chunk_nnz(nnz_out, p->cu_count);
+  p->pout_nchunks = (int)(((long long)nnz_out + p->pout_T - 1) / p->pout_T);
+  if (p->pout_nchunks > 0) {
+    if (hipMalloc((void**)&p->pout_chunk_row, sizeof(int) * (size_t)p->pout_nchunks) != hipSuccess) {
+      free_panels(p); return GCN_ERR_ALLOC;
+    }
+    if (gcn::launch_plan_chunk_rows(p->pout_rowptr, p->m, p->pout_T, p->pout_nchunks, p->pout_chunk_row,
+                                    st) != hipSuccess) { free_panels(p); return GCN_ERR_HIP; }
+  }
+  p->panel_R = R;
   return GCN_OK;
 }
 

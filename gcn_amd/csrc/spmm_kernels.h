@@ -27,6 +27,7 @@ struct SpmmArgs {
   // kernel (not the fix-up) — the live kernel timing bench.py reports (null = off)
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
   int tile_cols = 0;       // feature-column tile per pass: 0 auto, else 64 / 128 / 256
+  int accumulate = 0;      // 1: C += A*B (C already holds another part of the product); epilogue after the add
   int blocks_per_cu = 8;   // persistent-grid size: 256-thread blocks per CU (1..8); < 8 leaves
                            // wave slots free for a concurrent kernel (the RCCL all-gather)
 };
@@ -44,7 +45,13 @@ hipError_t launch_spmm_narrow(const SpmmArgs& a, int nblocks, bool epi, hipStrea
 // spmm_panel.hip — LDS-staged feature tiles per row panel (near-diagonal matrices)
 hipError_t panel_plan(const int* rowptr, const int* col, int m, int n, int R, int* w0_dev,
                       unsigned long long* inside_host, hipStream_t st);
-hipError_t launch_spmm_panel(const SpmmArgs& a, int R, const int* panel_w0, hipStream_t s);
+hipError_t panel_split(const int* rowptr, const int* col, const float* val, const int* w0_dev, int m,
+                       int R, int* in_rowptr, int* out_rowptr, int* in_off, float* in_val,
+                       int* out_col, float* out_val, int* nnz_in_host, hipStream_t st);
+hipError_t launch_panel_in(const int* in_rowptr, const int* in_off, const float* in_val, const float* B,
+                           float* C, const int* panel_w0, int m, int n, int k, int R, int tile,
+                           hipStream_t s);
+hipError_t launch_panel_epilogue(float* C, const float* bias, int relu, int m, int k, hipStream_t s);
 
 // slicing.hip
 hipError_t build_sliced_csr(const int* rowptr, const int* col, const float* val, int m, int n,

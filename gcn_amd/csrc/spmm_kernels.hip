@@ -108,7 +108,7 @@ spmm_chunk_kernel(const int* __restrict__ g_rowptr, const int* __restrict__ g_co
                   float* __restrict__ g_C, float* __restrict__ g_P,
                   const int* __restrict__ g_chunk_row, const float* __restrict__ g_bias,
                   const int* __restrict__ g_nnz_dev,
-                  int relu, int nchunks, int T, int m, int nnz, int kk, int col_tile) {
+                  int relu, int nchunks, int T, int m, int nnz, int kk, int col_tile, int accumulate) {
   // drop-in (flexspmm) mode: the host does not know nnz; it lives in rowptr[m] and
   // the values follow the column indices in one buffer (api.cpp, csr2tile layout)
   if (g_nnz_dev) {
@@ -173,6 +173,14 @@ spmm_chunk_kernel(const int* __restrict__ g_rowptr, const int* __restrict__ g_co
       if (head) {
         if (active) store_vec<VEC>(a.P + (size_t)(2 * c) * k + fcol, acc);
       } else {
+        if (accumulate) {                   // C already holds another part of the product (beta = 1)
+          float old[VEC];
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) old[i] = 0.f;
+          if (active) load_vec<VEC>(a.C + (size_t)r * k + fcol, old);
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) acc[i] += old[i];
+        }
         if (EPI) {
 #pragma unroll
           for (int i = 0; i < VEC; ++i) {
@@ -266,7 +274,7 @@ __global__ void __launch_bounds__(256)
 spmm_fixup_kernel(const int* __restrict__ g_rowptr, const float* __restrict__ g_P,
                   float* __restrict__ g_C, const int* __restrict__ g_chunk_row,
                   const float* __restrict__ g_bias, const int* __restrict__ g_nnz_dev,
-                  int relu, int nchunks, int T, int kk) {
+                  int relu, int nchunks, int T, int kk, int accumulate) {
   if (g_nnz_dev) nchunks = (int)(((long long)(*g_nnz_dev) + T - 1) / T);
   const struct {
     const int* __restrict__ rowptr; const float* __restrict__ P; float* __restrict__ C;
@@ -285,6 +293,7 @@ spmm_fixup_kernel(const int* __restrict__ g_rowptr, const float* __restrict__ g_
   for (int x = lane; x < a.k; x += 64) {
     float s = a.P[(size_t)(2 * (c - 1) + 1) * k + x];
     for (int cc = c; cc <= c1; ++cc) s += a.P[(size_t)(2 * cc) * k + x];
+    if (accumulate) s += a.C[(size_t)r * k + x];
     if (EPI) {
       if (a.bias) s += a.bias[x];
       if (a.relu) s = fmaxf(s, 0.f);
@@ -346,7 +355,7 @@ static hipError_t launch_main(const SpmmArgs& a, int nblocks, bool epi, hipStrea
   const int tiles = (a.k + 64 * VEC - 1) / (64 * VEC);
   dim3 grid(nblocks), block(256);
 #define GCN_MAIN_ARGS a.rowptr, a.col, a.val, a.B, a.C, a.P, a.chunk_row, a.bias, a.nnz_dev, \
-                      a.relu, a.nchunks, a.T, a.m, a.nnz, a.k, t
+                      a.relu, a.nchunks, a.T, a.m, a.nnz, a.k, t, a.accumulate
   // buffer addressing needs every byte offset into B to fit 32 bits
   const bool buf = VEC == 1 && (unsigned long long)a.n * (unsigned long long)a.k * 4ull < 0xFFFFFFF0ull;
   for (int t = 0; t < tiles; ++t) {
@@ -420,9 +429,9 @@ hipError_t launch_spmm(const SpmmArgs& a, int cu_count, hipStream_t s) {
   if (ng > 1) {
     const int nb = (ng - 1 + 3) / 4;
     if (epi) spmm_fixup_kernel<true><<<nb, 256, 0, s>>>(a.rowptr, a.P, a.C, a.chunk_row, a.bias,
-                                                        a.nnz_dev, a.relu, a.nchunks, a.T, a.k);
+                                                        a.nnz_dev, a.relu, a.nchunks, a.T, a.k, a.accumulate);
     else     spmm_fixup_kernel<false><<<nb, 256, 0, s>>>(a.rowptr, a.P, a.C, a.chunk_row, a.bias,
-                                                         a.nnz_dev, a.relu, a.nchunks, a.T, a.k);
+                                                         a.nnz_dev, a.relu, a.nchunks, a.T, a.k, a.accumulate);
     e = hipGetLastError();
   }
   return e;

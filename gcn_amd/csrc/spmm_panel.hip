@@ -2,23 +2,28 @@
 // column ranges near their rows (graphs with community structure after Rabbit / RCM / Gorder
 // renumbering).
 //
-// A workgroup of 16 waves owns a PANEL of R consecutive rows.  At plan time every panel gets the
-// column WINDOW (W = 512 consecutive columns, start a multiple of 128) that covers most of its
-// non-zeros (panel_windows_kernel).  At run time the workgroup copies the window's feature rows for
-// one 64-column tile — W x 64 floats = 128 KiB of the CU's 160 KiB LDS — with coalesced loads, then
-// every wave sums whole rows.  Per 64-entry block of a row the wave splits the lanes into "in the
-// window" / "outside" with one vector compare and compacts both groups in registers (ballot, mbcnt
-// rank, ds_permute): outside entries are whole-row gathers from L2/HBM, issued first, inside entries
-// are conflict-free ds_read_b32 from the staged tile, summed while the gathers are in flight.  On a renumbered
-// community graph most non-zeros hit the window, and the L2->CU traffic that bounds
-// spmm_chunk_kernel shrinks by the window hit rate.
-//
-// Rows are owned by one wave (no partial slab, no atomics); a row is summed as one chain over its
-// outside entries plus one chain over its inside entries per 64-entry block, in a fixed order —
-// deterministic.  Rows longer than LONG_ROW non-zeros (hubs) are summed by all 16 waves together
-// (strided blocks, per-wave partials combined through LDS in wave order).  Whether the path is used
-// at all is decided at plan time from the measured window coverage; it is never a correctness question.
+// Plan time (device):
+//   * every PANEL of R = 128 consecutive rows gets the column WINDOW — W = 512 consecutive columns,
+//     start a multiple of 128 — that covers most of its non-zeros (panel_windows_kernel: one LDS
+//     histogram per panel);
+//   * the matrix is split  A = A_in + A_out :  A_in holds the entries inside their panel's window
+//     (stored as byte offsets into the staged tile), A_out the rest (an ordinary CSR with its own
+//     chunk plan).  Splitting keeps the two access patterns apart: a first version that mixed LDS
+//     reads and L2/HBM gathers in one loop was latency-bound at 4 waves per SIMD and lost to the
+//     chunk kernel.
+// Run time, per 64-column tile:
+//   1. spmm_panel_in_kernel: a 16-wave workgroup stages the window's feature rows (W x 64 floats =
+//      128 KiB of the CU's 160 KiB LDS) with coalesced loads, then every wave sums whole rows of
+//      A_in from LDS only — v_readlane + conflict-free ds_read_b32 + FMA, no global gather at all —
+//      and writes C (raw sums, zeros for rows without staged entries);
+//   2. spmm_chunk_kernel on A_out in ACCUMULATE mode adds the out-of-window part (and applies the
+//      bias/ReLU epilogue).
+// Rows of A_in are owned by one wave and summed in CSR order; hub rows (> LONG_ROW staged entries)
+// are summed by all 16 waves (strided blocks, partials combined through LDS in wave order).
+// Deterministic, no atomics.  Used only when asked for / when the measured window coverage says it
+// pays; never a correctness question.
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 #include <stdint.h>
 #include "spmm_kernels.h"
 
@@ -29,7 +34,6 @@ constexpr int PANEL_W = 512;              // window: 512 feature rows x 64 colum
 constexpr int PANEL_BIN = 128;            // window starts are multiples of this
 constexpr int PANEL_MAX_BINS = 8192;      // histogram bins a plan-time workgroup can hold (n <= 1 M)
 constexpr int PANEL_LONG_ROW = 2048;      // rows above this are summed by the whole workgroup
-
 
 __device__ __forceinline__ int psgpr(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
@@ -54,32 +58,27 @@ panel_windows_kernel(const int* __restrict__ rowptr, const int* __restrict__ col
   const int r0 = p * R, r1 = min(m, r0 + R);
   const int nbins = (n + PANEL_BIN - 1) / PANEL_BIN;
   const int e0 = rowptr[r0], e1 = rowptr[r1];
+  if (threadIdx.x == 0) best_cnt = 0;
   if (nbins > PANEL_MAX_BINS) {                       // too wide to histogram here: diagonal window
-    const int w0 = panel_diag_window(r0, R, m, n);
-    unsigned int c = 0;
-    for (int e = e0 + threadIdx.x; e < e1; e += blockDim.x) c += (unsigned)(col[e] - w0) < (unsigned)PANEL_W;
-    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
-    if ((threadIdx.x & 63) == 0 && c) atomicAdd(inside, (unsigned long long)c);
-    if (threadIdx.x == 0) w0_out[p] = w0;
-    return;
-  }
-  for (int i = threadIdx.x; i < nbins; i += blockDim.x) hist[i] = 0;
-  __syncthreads();
-  for (int e = e0 + threadIdx.x; e < e1; e += blockDim.x) atomicAdd(&hist[col[e] / PANEL_BIN], 1u);
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const int span = PANEL_W / PANEL_BIN;             // 4 bins
-    unsigned int run = 0, best = 0;
-    int best_bin = 0;
-    for (int b = 0; b < nbins; ++b) {
-      run += hist[b];
-      if (b >= span) run -= hist[b - span];
-      if (run > best) { best = run; best_bin = max(0, b - span + 1); }
+    if (threadIdx.x == 0) best_w0 = panel_diag_window(r0, R, m, n);
+  } else {
+    for (int i = threadIdx.x; i < nbins; i += blockDim.x) hist[i] = 0;
+    __syncthreads();
+    for (int e = e0 + threadIdx.x; e < e1; e += blockDim.x) atomicAdd(&hist[col[e] / PANEL_BIN], 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int span = PANEL_W / PANEL_BIN;           // 4 bins
+      unsigned int run = 0, best = 0;
+      int best_bin = 0;
+      for (int b = 0; b < nbins; ++b) {
+        run += hist[b];
+        if (b >= span) run -= hist[b - span];
+        if (run > best) { best = run; best_bin = max(0, b - span + 1); }
+      }
+      long long w0 = (long long)best_bin * PANEL_BIN;
+      if (w0 > (long long)n - PANEL_W) w0 = max(0LL, (long long)n - PANEL_W);
+      best_w0 = (int)w0;
     }
-    long long w0 = (long long)best_bin * PANEL_BIN;
-    if (w0 > (long long)n - PANEL_W) w0 = max(0LL, (long long)n - PANEL_W);
-    best_w0 = (int)w0;
-    best_cnt = 0;
   }
   __syncthreads();
   // exact count for the chosen window (clamping at the matrix edge can move it off bin alignment)
@@ -95,17 +94,67 @@ panel_windows_kernel(const int* __restrict__ rowptr, const int* __restrict__ col
   }
 }
 
-template <bool EPI, bool BUF>
+// plan time: per-row count of staged (in-window) entries; one wave per row
+__global__ void __launch_bounds__(256)
+panel_split_count_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
+                         const int* __restrict__ panel_w0, int m, int R,
+                         int* __restrict__ cnt_in, int* __restrict__ cnt_out) {
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int nw = gridDim.x * 4;
+  for (int r = wave; r < m; r += nw) {
+    const int w0 = panel_w0[r / R];
+    const int beg = rowptr[r], end = rowptr[r + 1];
+    int c = 0;
+    for (int e = beg + lane; e < end; e += 64) c += (unsigned)(col[e] - w0) < (unsigned)PANEL_W;
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    if (lane == 0) { cnt_in[r] = c; cnt_out[r] = end - beg - c; }
+  }
+}
+
+// plan time: order-preserving split of every row into its staged part (byte offset into the LDS
+// tile) and the rest (column index); one wave per row
+__global__ void __launch_bounds__(256)
+panel_split_scatter_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
+                           const float* __restrict__ val, const int* __restrict__ panel_w0,
+                           const int* __restrict__ in_rowptr, const int* __restrict__ out_rowptr,
+                           int m, int R, int* __restrict__ in_off, float* __restrict__ in_val,
+                           int* __restrict__ out_col, float* __restrict__ out_val) {
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int nw = gridDim.x * 4;
+  for (int r = wave; r < m; r += nw) {
+    const int w0 = panel_w0[r / R];
+    const int beg = rowptr[r], end = rowptr[r + 1];
+    int pin = in_rowptr[r], pout = out_rowptr[r];
+    for (int base = beg; base < end; base += 64) {
+      const bool valid = base + lane < end;
+      const int c = valid ? col[base + lane] : 0;
+      const float v = valid ? val[base + lane] : 0.f;
+      const bool in = valid && (unsigned)(c - w0) < (unsigned)PANEL_W;
+      const unsigned long long mi = __ballot(in), mo = __ballot(valid && !in);
+      const int ri = __builtin_amdgcn_mbcnt_hi((unsigned)(mi >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mi, 0));
+      const int ro = __builtin_amdgcn_mbcnt_hi((unsigned)(mo >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mo, 0));
+      if (in) { in_off[pin + ri] = (c - w0) * 256; in_val[pin + ri] = v; }
+      else if (valid) { out_col[pout + ro] = c; out_val[pout + ro] = v; }
+      pin += __builtin_popcountll(mi);
+      pout += __builtin_popcountll(mo);
+    }
+  }
+}
+
+// run time: C[r, tile] = sum over the staged entries of row r, from LDS only
 __global__ void __launch_bounds__(PANEL_WAVES * 64)
-spmm_panel_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
-                  const float* __restrict__ val, const float* __restrict__ B, float* __restrict__ C,
-                  const float* __restrict__ bias, const int* __restrict__ panel_w0,
-                  int relu, int m, int n, int k, int R, int col_tile) {
+spmm_panel_in_kernel(const int* __restrict__ in_rowptr, const int* __restrict__ in_off,
+                     const float* __restrict__ in_val, const float* __restrict__ B,
+                     float* __restrict__ C, const int* __restrict__ panel_w0,
+                     int m, int n, int k, int R, int col_tile) {
   extern __shared__ float lds[];                    // [PANEL_W][64] tile + [PANEL_WAVES][64] scratch
-  float* tile = lds;
+  const char* tile = reinterpret_cast<const char*>(lds);
   float* scratch = lds + PANEL_W * 64;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
+  const int lane4 = lane * 4;
   const int w = psgpr(tid >> 6);
   const int r0 = blockIdx.x * R;
   const int r1 = min(m, r0 + R);
@@ -115,122 +164,64 @@ spmm_panel_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
   const bool active = fcol < k;
   const size_t kk = (size_t)k;
 
-  // ---- stage the window's feature tile (each wave copies whole 256-B row segments) -------------
-  for (int i = tid; i < wn * 64; i += PANEL_WAVES * 64) {
-    const int rr = i >> 6, cc = col_tile * 64 + (i & 63);
-    tile[i] = cc < k ? B[(size_t)(w0 + rr) * kk + cc] : 0.f;
+  // ---- stage the window's feature tile: 8 independent row-segment loads per thread in flight ----
+  for (int i0 = tid; i0 < wn * 64; i0 += PANEL_WAVES * 64 * 8) {
+    float t[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int i = i0 + q * PANEL_WAVES * 64;
+      const int rr = i >> 6, cc = col_tile * 64 + (i & 63);
+      t[q] = (i < wn * 64 && cc < k) ? B[(size_t)(w0 + rr) * kk + cc] : 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int i = i0 + q * PANEL_WAVES * 64;
+      if (i < wn * 64) lds[i] = t[q];
+    }
   }
   __syncthreads();
 
-  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(B), 0, 0xFFFFFFFFu, 0x00020000);
-  const int voff = (active ? fcol : 0) * 4;
-  const unsigned row_bytes = (unsigned)k * 4u;
-  const float* __restrict__ Bl = B + (active ? fcol : 0);
-  const float bias_f = (EPI && bias && active) ? bias[fcol] : 0.f;
-
-  // sum of the non-zeros [beg, end) taken in 64-entry blocks `stride` blocks apart, first block `first`.
-  // Per block the 64 (col, val) pairs are COMPACTED in registers — staged (in-window) entries to
-  // lanes [0, nin), the others to [nin, cnt), each group in its original order (one ballot + mbcnt
-  // rank + ds_permute) — and their byte offsets are pre-multiplied with one vector op, so that the
-  // two inner loops are plain counted loops of v_readlane + load + FMA like spmm_chunk_kernel's.
-  const int lane4 = lane * 4;
+  // sum of the staged entries [beg, end) in 64-entry blocks `stride` blocks apart, first block `first`
   auto row_sum = [&](int beg, int end, int first, int stride) -> float {
     float acc = 0.f;
     int base = beg + first * 64;
-    int cj_nx = 0;
+    int oj_nx = 0;
     float vj_nx = 0.f;
-    if (base + lane < end) { cj_nx = col[base + lane]; vj_nx = val[base + lane]; }
+    if (base + lane < end) { oj_nx = in_off[base + lane]; vj_nx = in_val[base + lane]; }
     for (; base < end; base += stride * 64) {
       const int cnt = min(64, end - base);
-      const int cj = cj_nx;
+      const int oj = oj_nx;
       const int vji = __builtin_bit_cast(int, vj_nx);
-      const int nb = base + stride * 64;              // (col, val) of the next block, one block ahead
-      if (nb + lane < end) { cj_nx = col[nb + lane]; vj_nx = val[nb + lane]; }
-      const bool valid = lane < cnt;
-      const bool in = valid && (unsigned)(cj - w0) < (unsigned)wn;
-      const unsigned long long m_in  = __ballot(in);
-      const unsigned long long m_out = __ballot(valid && !in);
-      const int nin = __builtin_popcountll(m_in);
-      const int rin  = __builtin_amdgcn_mbcnt_hi((unsigned)(m_in >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m_in, 0));
-      const int rout = __builtin_amdgcn_mbcnt_hi((unsigned)(m_out >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m_out, 0));
-      const int dest = in ? rin : (valid ? nin + rout : lane);
-      // byte offset of the entry: into the LDS tile (staged) or into B (elsewhere)
-      // (flat addressing, B >= 4 GiB: the column index itself travels, the 64-bit product is formed later)
-      const int off = in ? (cj - w0) * 256 : (BUF ? (int)((unsigned)cj * row_bytes) : cj);
-      const int offp = __builtin_amdgcn_ds_permute(dest * 4, valid ? off : 0);
-      const int valp = __builtin_amdgcn_ds_permute(dest * 4, valid ? vji : 0);
-
-      // ---- first batch of outside gathers goes out before the staged entries are summed --------
-      int jo = nin;
-      float bo[16];
-      int no = min(16, cnt - jo);
-      if (no > 0) {
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-          const int so = (u < no) ? __builtin_amdgcn_readlane(offp, (jo + u) & 63) : 0;
-          if (BUF) bo[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, so, 0));
-          else     bo[u] = Bl[(size_t)so * kk];
-        }
-      }
-      // ---- staged entries: LDS reads, 16 at a time ----------------------------------------------
-      for (int j = 0; j < nin; j += 16) {
-        float bi[16];
-        if (j + 16 <= nin) {
-#pragma unroll
-          for (int u = 0; u < 16; ++u)
-            bi[u] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(tile) +
-                        __builtin_amdgcn_readlane(offp, j + u) + lane4);
-#pragma unroll
-          for (int u = 0; u < 16; ++u)
-            acc = fmaf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(valp, j + u)), bi[u], acc);
-        } else {
-          const int ni = nin - j;
-#pragma unroll
-          for (int u = 0; u < 16; ++u) {
-            const int so = (u < ni) ? __builtin_amdgcn_readlane(offp, (j + u) & 63) : 0;
-            bi[u] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(tile) + so + lane4);
-          }
-#pragma unroll
-          for (int u = 0; u < 16; ++u)
-            if (u < ni) acc = fmaf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(valp, (j + u) & 63)), bi[u], acc);
-        }
-      }
-      // ---- consume the gathers; further batches if the block has more than 16 outside entries ----
-      while (true) {
+      const int nb = base + stride * 64;              // next block, fetched one block ahead
+      oj_nx = 0; vj_nx = 0.f;
+      if (nb + lane < end) { oj_nx = in_off[nb + lane]; vj_nx = in_val[nb + lane]; }
+      int j = 0;
+      for (; j + 16 <= cnt; j += 16) {                // full batches: 16 LDS reads, then 16 FMAs
+        float b[16];
 #pragma unroll
         for (int u = 0; u < 16; ++u)
-          if (u < no) acc = fmaf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(valp, (jo + u) & 63)), bo[u], acc);
-        jo += 16;
-        if (jo >= cnt) break;
-        no = min(16, cnt - jo);
+          b[u] = *reinterpret_cast<const float*>(tile + __builtin_amdgcn_readlane(oj, j + u) + lane4);
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-          const int so = (u < no) ? __builtin_amdgcn_readlane(offp, (jo + u) & 63) : 0;
-          if (BUF) bo[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, so, 0));
-          else     bo[u] = Bl[(size_t)so * kk];
-        }
+        for (int u = 0; u < 16; ++u)
+          acc = fmaf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(vji, j + u)), b[u], acc);
       }
+      for (; j < cnt; ++j)                            // tail of the row's last block
+        acc = fmaf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(vji, j)),
+                   *reinterpret_cast<const float*>(tile + __builtin_amdgcn_readlane(oj, j) + lane4), acc);
     }
     return acc;
-  };
-  auto finish = [&](int r, float acc) {
-    if (EPI) {
-      acc += bias_f;
-      if (relu) acc = fmaxf(acc, 0.f);
-    }
-    if (active) C[(size_t)r * kk + fcol] = acc;
   };
 
   // ---- ordinary rows: one wave per row ---------------------------------------------------------
   for (int r = r0 + w; r < r1; r += PANEL_WAVES) {
-    const int beg = rowptr[r], end = rowptr[r + 1];
+    const int beg = in_rowptr[r], end = in_rowptr[r + 1];
     if (end - beg > PANEL_LONG_ROW) continue;
-    finish(r, row_sum(beg, end, 0, 1));
+    const float acc = row_sum(beg, end, 0, 1);
+    if (active) C[(size_t)r * kk + fcol] = acc;
   }
   // ---- hub rows: all waves together (every wave walks the same list, so the barriers match) ----
   for (int r = r0; r < r1; ++r) {
-    const int beg = rowptr[r], end = rowptr[r + 1];
+    const int beg = in_rowptr[r], end = in_rowptr[r + 1];
     if (end - beg <= PANEL_LONG_ROW) continue;
     const float part = row_sum(beg, end, w, PANEL_WAVES);
     __syncthreads();                                 // scratch free again
@@ -239,8 +230,20 @@ spmm_panel_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
     if (w == 0) {
       float acc = 0.f;
       for (int i = 0; i < PANEL_WAVES; ++i) acc += scratch[i * 64 + lane];   // wave order: deterministic
-      finish(r, acc);
+      if (active) C[(size_t)r * kk + fcol] = acc;
     }
+  }
+}
+
+// C = act(C + bias): the epilogue alone, for when the out-of-window part is empty
+__global__ void panel_epilogue_kernel(float* __restrict__ C, const float* __restrict__ bias, int relu,
+                                      long long total, int k) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (; i < total; i += stride) {
+    float s = C[i] + (bias ? bias[i % k] : 0.f);
+    if (relu) s = fmaxf(s, 0.f);
+    C[i] = s;
   }
 }
 
@@ -263,38 +266,71 @@ hipError_t panel_plan(const int* rowptr, const int* col, int m, int n, int R, in
   return e;
 }
 
-hipError_t launch_spmm_panel(const SpmmArgs& a, int R, const int* panel_w0, hipStream_t s) {
-  if (a.m <= 0 || a.k <= 0) return hipSuccess;
+// plan time: A = A_in + A_out.  Outputs are caller-allocated device arrays: in_rowptr/out_rowptr
+// [m+1], in_off/in_val [nnz_in], out_col/out_val [nnz - nnz_in].  Pass 1 (entry arrays null) fills
+// the row pointers and *nnz_in_host; pass 2 scatters the entries.
+hipError_t panel_split(const int* rowptr, const int* col, const float* val, const int* w0_dev, int m,
+                       int R, int* in_rowptr, int* out_rowptr, int* in_off, float* in_val,
+                       int* out_col, float* out_val, int* nnz_in_host, hipStream_t st) {
+  hipError_t e = hipSuccess;
+  int nb = (m + 3) / 4;
+  if (nb > 16384) nb = 16384;
+  if (!in_off) {                                      // pass 1: counts -> row pointers
+    int *ci = nullptr, *co = nullptr;
+    void* tmp = nullptr;
+    size_t tb = 0, tb2 = 0;
+    auto done = [&](hipError_t x) {
+      if (ci) (void)hipFree(ci);
+      if (co) (void)hipFree(co);
+      if (tmp) (void)hipFree(tmp);
+      return x;
+    };
+    if ((e = hipMalloc((void**)&ci, sizeof(int) * (size_t)(m + 1))) != hipSuccess) return done(e);
+    if ((e = hipMalloc((void**)&co, sizeof(int) * (size_t)(m + 1))) != hipSuccess) return done(e);
+    (void)hipMemsetAsync(ci + m, 0, sizeof(int), st);
+    (void)hipMemsetAsync(co + m, 0, sizeof(int), st);
+    panel_split_count_kernel<<<nb, 256, 0, st>>>(rowptr, col, w0_dev, m, R, ci, co);
+    if ((e = hipGetLastError()) != hipSuccess) return done(e);
+    if ((e = hipcub::DeviceScan::ExclusiveSum(nullptr, tb, ci, in_rowptr, m + 1, st)) != hipSuccess) return done(e);
+    if ((e = hipcub::DeviceScan::ExclusiveSum(nullptr, tb2, co, out_rowptr, m + 1, st)) != hipSuccess) return done(e);
+    if (tb2 > tb) tb = tb2;
+    if ((e = hipMalloc(&tmp, tb ? tb : 16)) != hipSuccess) return done(e);
+    if ((e = hipcub::DeviceScan::ExclusiveSum(tmp, tb, ci, in_rowptr, m + 1, st)) != hipSuccess) return done(e);
+    if ((e = hipcub::DeviceScan::ExclusiveSum(tmp, tb, co, out_rowptr, m + 1, st)) != hipSuccess) return done(e);
+    if ((e = hipMemcpyAsync(nnz_in_host, in_rowptr + m, sizeof(int), hipMemcpyDeviceToHost, st)) != hipSuccess) return done(e);
+    return done(hipStreamSynchronize(st));
+  }
+  panel_split_scatter_kernel<<<nb, 256, 0, st>>>(rowptr, col, val, w0_dev, in_rowptr, out_rowptr, m, R,
+                                                 in_off, in_val, out_col, out_val);
+  if ((e = hipGetLastError()) != hipSuccess) return e;
+  return hipStreamSynchronize(st);
+}
+
+// staged part: C[:, tile] = A_in * B[:, tile] for one 64-column tile (raw sums, every row written)
+hipError_t launch_panel_in(const int* in_rowptr, const int* in_off, const float* in_val, const float* B,
+                           float* C, const int* panel_w0, int m, int n, int k, int R, int tile,
+                           hipStream_t s) {
   const size_t lds_bytes = sizeof(float) * (size_t)(PANEL_W * 64 + PANEL_WAVES * 64);
-  const bool epi = (a.bias != nullptr) || a.relu;
-  const bool buf = (unsigned long long)a.n * (unsigned long long)a.k * 4ull < 0xFFFFFFF0ull;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e;
-#define GCN_PANEL_ATTR(K) \
-    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&K), \
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)) != hipSuccess) return e;
-    GCN_PANEL_ATTR((spmm_panel_kernel<false, false>)) GCN_PANEL_ATTR((spmm_panel_kernel<false, true>))
-    GCN_PANEL_ATTR((spmm_panel_kernel<true, false>))  GCN_PANEL_ATTR((spmm_panel_kernel<true, true>))
-#undef GCN_PANEL_ATTR
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_panel_in_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
     attr_done = true;
   }
-  const int panels = (a.m + R - 1) / R;
-  const int tiles = (a.k + 63) / 64;
-  hipError_t e;
-  if (a.ev_start && (e = hipEventRecord(a.ev_start, s)) != hipSuccess) return e;
-  for (int t = 0; t < tiles; ++t) {
-#define GCN_PANEL_ARGS a.rowptr, a.col, a.val, a.B, a.C, a.bias, panel_w0, a.relu, a.m, a.n, a.k, R, t
-    dim3 grid(panels), block(PANEL_WAVES * 64);
-    if (epi) { if (buf) spmm_panel_kernel<true, true><<<grid, block, lds_bytes, s>>>(GCN_PANEL_ARGS);
-               else     spmm_panel_kernel<true, false><<<grid, block, lds_bytes, s>>>(GCN_PANEL_ARGS); }
-    else     { if (buf) spmm_panel_kernel<false, true><<<grid, block, lds_bytes, s>>>(GCN_PANEL_ARGS);
-               else     spmm_panel_kernel<false, false><<<grid, block, lds_bytes, s>>>(GCN_PANEL_ARGS); }
-#undef GCN_PANEL_ARGS
-  }
-  if ((e = hipGetLastError()) != hipSuccess) return e;
-  if (a.ev_stop && (e = hipEventRecord(a.ev_stop, s)) != hipSuccess) return e;
-  return hipSuccess;
+  const int panels = (m + R - 1) / R;
+  spmm_panel_in_kernel<<<dim3(panels), dim3(PANEL_WAVES * 64), lds_bytes, s>>>(
+      in_rowptr, in_off, in_val, B, C, panel_w0, m, n, k, R, tile);
+  return hipGetLastError();
+}
+
+hipError_t launch_panel_epilogue(float* C, const float* bias, int relu, int m, int k, hipStream_t s) {
+  const long long total = (long long)m * k;
+  if (total <= 0 || (!bias && !relu)) return hipSuccess;
+  int nb = (int)((total + 255) / 256);
+  if (nb > 8192) nb = 8192;
+  panel_epilogue_kernel<<<nb, 256, 0, s>>>(C, bias, relu, total, k);
+  return hipGetLastError();
 }
 
 }  // namespace gcn

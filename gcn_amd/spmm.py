@@ -116,7 +116,7 @@ class CsrAdjacency:
         """LDS-staged row panels (gcn_spmm_plan_enable_panels): 0 off, 1 on, -1 automatic."""
         with torch.cuda.device(self.device):
             st = _lib.load().gcn_spmm_plan_enable_panels(self.plan, _ptr(self.rowptr), _ptr(self.col),
-                                                         int(mode), _stream_ptr(self.device))
+                                                         _ptr(self.val), int(mode), _stream_ptr(self.device))
         _lib.check(st, "gcn_spmm_plan_enable_panels")
 
     @property

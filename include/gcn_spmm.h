@@ -112,12 +112,14 @@ int32_t gcn_spmm_plan_num_slices(const gcn_spmm_plan_t* plan);
 
 /* LDS-staged row panels (optional): for matrices whose non-zeros sit near the diagonal (community
  * graphs after Rabbit / RCM / Gorder renumbering) a workgroup stages the feature rows of its panel's
- * column window (512 rows x 64 columns = 128 KiB of LDS) once and serves the in-window non-zeros
- * from LDS, the rest by the usual gather.  mode 0 = off, 1 = on, -1 = on iff at least half of the
+ * column window (512 rows x 64 columns = 128 KiB of LDS) once and sums the in-window non-zeros
+ * from LDS; the matrix is split on the device into that staged part and the rest, which the chunk
+ * kernel adds in accumulate mode (the split copy costs one extra copy of col/val).  mode 0 = off, 1 = on, -1 = on iff at least half of the
  * non-zeros fall inside their panel's window (measured here, on the device).  When on it is used for
  * k > 32 and takes precedence over slicing; results stay deterministic (rows are summed in CSR order). */
 int gcn_spmm_plan_enable_panels(gcn_spmm_plan_t* plan, const int32_t* rowptr_dev,
-                                const int32_t* col_dev, int32_t mode, void* stream);
+                                const int32_t* col_dev, const float* val_dev, int32_t mode,
+                                void* stream);
 int32_t gcn_spmm_plan_panel_rows(const gcn_spmm_plan_t* plan);       /* rows per panel, 0 = off */
 double gcn_spmm_plan_panel_coverage(const gcn_spmm_plan_t* plan);    /* fraction of nnz inside windows */
 

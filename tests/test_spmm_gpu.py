@@ -514,3 +514,26 @@ def test_panels_stay_off_for_unstructured_graphs_and_work_when_forced():
     forced = _adj(rowptr, col, val, m, n, panels=1)           # non-square, coverage ~ 17 %: still exact
     B = np.random.default_rng(0).standard_normal((n, k)).astype(np.float32)
     assert rel_err(forced.matmul_raw(torch.from_numpy(B).to(_dev())).cpu().numpy(), oracle_spmm(rowptr, col, val, B)) <= TOL
+
+
+def test_panels_with_everything_staged_and_with_nothing_staged():
+    """both degenerate splits: A_out empty (epilogue-only second phase) and A_in (almost) empty"""
+    d = _dev()
+    n, k = 2000, 96
+    rowptr, col, val = _banded_csr(n, 100, 0, seed=3)             # every entry inside its panel's window
+    rng = np.random.default_rng(4)
+    B = rng.standard_normal((n, k)).astype(np.float32)
+    bias = rng.standard_normal(k).astype(np.float32)
+    adj = _adj(rowptr, col, val, n, n, panels=1)
+    assert adj.panel_coverage == 1.0
+    Cref = oracle_spmm(rowptr, col, val, B)
+    assert rel_err(adj.matmul_raw(torch.from_numpy(B).to(d)).cpu().numpy(), Cref) <= TOL
+    C2 = adj.matmul_raw(torch.from_numpy(B).to(d), bias=torch.from_numpy(bias).to(d), relu=True).cpu().numpy()
+    assert rel_err(C2, np.maximum(Cref + bias, 0)) <= TOL
+    # columns far from the rows: (almost) nothing staged, everything through the accumulate path
+    m2, n2 = 1500, 200000
+    rp2, ci2, va2 = random_csr(m2, n2, 30000, seed=6, empty_rows=0.2)
+    B2 = rng.standard_normal((n2, k)).astype(np.float32)
+    adj2 = _adj(rp2, ci2, va2, m2, n2, panels=1)
+    assert adj2.panel_coverage < 0.05
+    assert rel_err(adj2.matmul_raw(torch.from_numpy(B2).to(d)).cpu().numpy(), oracle_spmm(rp2, ci2, va2, B2)) <= TOL
