@@ -42,6 +42,10 @@ int pick_vec(int k, int tile_cols, const void* B, const void* C, const void* P);
 // spmm_narrow.hip — k <= 32: several non-zeros per gather instruction
 hipError_t launch_spmm_narrow(const SpmmArgs& a, int nblocks, bool epi, hipStream_t s);
 
+// spmm_quad.hip — 64-column tile, four non-zeros per 16-byte-per-lane gather instruction
+bool spmm_quad_eligible(const SpmmArgs& a);
+hipError_t launch_spmm_quad(const SpmmArgs& a, int nblocks, bool epi, hipStream_t s);
+
 // spmm_panel.hip — LDS-staged feature tiles per row panel (near-diagonal matrices)
 hipError_t panel_plan(const int* rowptr, const int* col, int m, int n, int R, int* w0_dev,
                       unsigned long long* inside_host, hipStream_t st);

@@ -413,6 +413,8 @@ hipError_t launch_spmm(const SpmmArgs& a, int cu_count, hipStream_t s) {
     case 4:  e = launch_main<4, 4>(a, nblocks, epi, s); break;
     case 2:  e = launch_main<2, 8>(a, nblocks, epi, s); break;
     default: {
+      static const bool quad_on = [] { const char* v = getenv("GCN_AMD_QUAD"); return !v || v[0] != '0'; }();
+      if (quad_on && spmm_quad_eligible(a)) { e = launch_spmm_quad(a, nblocks, epi, s); break; }
       // gathers in flight per wave for the 64-column tile (development knob GCN_AMD_U1;
       // measured on the sliced Reddit-shaped case, whole SpMM: U = 4 / 8 / 16 / 32 ->
       // 5.16 / 4.33 / 4.18 / 4.09 ms; 52 VGPRs at U = 32, still 8 waves per SIMD)

@@ -164,7 +164,7 @@ spmm_narrow_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
 // ---------------------------------------------------------------------------------------------
 template <int UU>
 __device__ __forceinline__ int dpp_row_bcast(int v) {
-  return __builtin_amdgcn_update_dpp(0, v, 0x150 + UU, 0xf, 0xf, false);       // row_newbcast:UU
+  return __builtin_amdgcn_mov_dpp(v, 0x150 + UU, 0xf, 0xf, true);               // row_newbcast:UU
 }
 
 template <bool EPI>

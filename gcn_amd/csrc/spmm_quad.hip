@@ -1,0 +1,223 @@
+// spmm_quad.hip — the 64-column-tile SpMM kernel with FOUR non-zeros per gather instruction.
+//
+// Why: on a dense band matrix (every gather an L1/L2 hit) the one-non-zero-per-instruction chunk
+// kernel (spmm_kernels.hip, VEC = 1) tops out at 67 G gathers/s — 9 CU-cycles per 256-byte row —
+// and the Reddit-shaped graph already runs at 92 % of that, so its time is set by what a gather
+// costs in the CU's vector-memory path, not by HBM.  16-byte-per-lane loads move the same cache
+// lines in fewer cycles (the 256-column tile reached 24.7 TB/s against 17.2 TB/s), but a
+// 256-column tile quadruples the gathered working set.  This kernel keeps the 64-column tile and
+// still issues 16-byte loads:
+//
+//   lane = sub*16 + f :  sub = 0..3 is which of the step's four non-zeros, f = 0..15 is which
+//   float4 of the 64-column slice.  One global_load_dwordx4 fetches FOUR different feature rows
+//   (4 x 256 B); each lane keeps a float4 partial sum for its (sub, f).
+//   The 64-entry (col, val) block is loaded transposed (lane s*16 + u holds entry 4u + s), so at
+//   step u a DPP row broadcast (row_newbcast:u, a modifier on a full-rate VALU op) hands every
+//   16-lane row exactly the non-zero it gathers for: no v_readlane / SGPR round trip, and a
+//   quarter of the vector instructions per non-zero of the VEC = 1 kernel.
+//   A row that ends — anywhere inside a step — is reduced over sub (two xor-shuffles per
+//   component) and written by the lanes sub == 0 as one 256-byte store.
+//
+// Chunk schedule, partial slab, fix-up, accumulate mode and epilogue are those of
+// spmm_kernels.hip (same plan, same arguments); the order of the additions inside a row differs
+// (4 interleaved chains + a tree), within the 1e-5 contract, and is fixed — results are
+// bit-reproducible run to run.  Needs k % 4 == 0, 16-byte aligned B/C/P, n < 2^24 and
+// n*k*4 < 4 GiB (24-bit multiply, 32-bit byte offsets); launch_spmm falls back to the VEC = 1
+// kernel otherwise.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "spmm_kernels.h"
+
+namespace gcn {
+
+typedef const int __attribute__((address_space(4)))* const_int_ptr;
+
+__device__ __forceinline__ int qsgpr(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+template <int UU>
+__device__ __forceinline__ int quad_bcast(int v) {
+  return __builtin_amdgcn_mov_dpp(v, 0x150 + UU, 0xf, 0xf, true);              // row_newbcast:UU (every lane has a source)
+}
+
+__device__ __forceinline__ float4 quad_reduce(float4 t) {
+  t.x += __shfl_xor(t.x, 16); t.y += __shfl_xor(t.y, 16);
+  t.z += __shfl_xor(t.z, 16); t.w += __shfl_xor(t.w, 16);
+  t.x += __shfl_xor(t.x, 32); t.y += __shfl_xor(t.y, 32);
+  t.z += __shfl_xor(t.z, 32); t.w += __shfl_xor(t.w, 32);
+  return t;
+}
+
+template <bool EPI>
+__global__ void __launch_bounds__(256)
+spmm_quad_kernel(const int* __restrict__ g_rowptr, const int* __restrict__ g_col,
+                 const float* __restrict__ g_val, const float* __restrict__ g_B,
+                 float* __restrict__ g_C, float* __restrict__ g_P,
+                 const int* __restrict__ g_chunk_row, const float* __restrict__ g_bias,
+                 const int* __restrict__ nnz_dev,
+                 int relu, int nchunks, int T, int m, int nnz, int k, int col_tile, int accumulate) {
+  if (nnz_dev) {                                    // drop-in (flexspmm) mode, see spmm_kernels.hip
+    nnz = *nnz_dev;
+    nchunks = (int)(((long long)nnz + T - 1) / T);
+    g_val = reinterpret_cast<const float*>(g_col) + nnz;
+  }
+  // Row pointers and chunk rows are read through the CONSTANT address space: wave-uniform loads
+  // from it always go through the scalar cache (s_load_dword), which keeps row_end / pos in SGPRs.
+  // (The kernel is too large for the compiler to prove by itself that its stores to C / P never
+  // clobber them.)  Nothing writes these arrays while the kernel runs.
+  const struct {
+    const_int_ptr rowptr; const int* __restrict__ col; const float* __restrict__ val;
+    const float* __restrict__ B; float* __restrict__ C; float* __restrict__ P;
+    const_int_ptr chunk_row; const float* __restrict__ bias;
+  } a = {(const_int_ptr)(uintptr_t)g_rowptr, g_col, g_val, g_B, g_C, g_P,
+         (const_int_ptr)(uintptr_t)g_chunk_row, g_bias};
+  const int lane = threadIdx.x & 63;
+  const int wib  = qsgpr(threadIdx.x >> 6);
+  const int sub  = lane >> 4;
+  const int f    = lane & 15;
+  const int fcol = col_tile * 64 + f * 4;           // first of this lane's four feature columns
+  const bool fok = fcol < k;                        // (k % 4 == 0: a float4 is all in or all out)
+  const bool writer = fok && sub == 0;
+  const int tl   = f * 4 + sub;                     // transposed position this lane loads
+
+  const int xcd           = blockIdx.x & 7;
+  const int wave_in_xcd   = (blockIdx.x >> 3) * 4 + wib;
+  const int waves_per_xcd = (gridDim.x >> 3) * 4;
+  const int c_lo = (int)(((long long)nchunks * xcd) >> 3);
+  const int c_hi = (int)(((long long)nchunks * (xcd + 1)) >> 3);
+
+  const unsigned row_bytes = (unsigned)k * 4u;
+  // lanes past k gather columns 0..3 of the same rows (valid memory) and never store
+  const unsigned foff = (unsigned)(fok ? fcol : 0) * 4u;
+  const char* __restrict__ Bb = reinterpret_cast<const char*>(a.B);
+  const size_t kk = (size_t)k;
+  float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (EPI) {
+    if (a.bias && fok) bias4 = *reinterpret_cast<const float4*>(a.bias + fcol);
+  }
+
+  for (int c = c_lo + wave_in_xcd; c < c_hi; c += waves_per_xcd) {
+    const int start = c * T;
+    const int end   = (int)min((long long)start + T, (long long)nnz);
+    int r = a.chunk_row[c];
+    int row_end    = a.rowptr[r + 1];
+    int row_end_nx = (r + 1 < m) ? a.rowptr[r + 2] : -1;
+    bool head = a.rowptr[r] < start;
+    int pos = start;
+    int last_flush = start;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);   // this lane's (sub, f) partial of the current row
+
+    auto flush = [&]() {
+      float4 t = quad_reduce(acc);
+      if (head) {
+        if (writer) *reinterpret_cast<float4*>(a.P + (size_t)(2 * c) * kk + fcol) = t;
+      } else {
+        float4* dst = reinterpret_cast<float4*>(a.C + (size_t)r * kk + fcol);
+        if (accumulate) {
+          if (writer) { const float4 o = *dst; t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w; }
+        }
+        if (EPI) {
+          t.x += bias4.x; t.y += bias4.y; t.z += bias4.z; t.w += bias4.w;
+          if (relu) { t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f); }
+        }
+        if (writer) *dst = t;
+      }
+      acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      head = false;
+      last_flush = pos;
+      ++r;
+      row_end    = row_end_nx;
+      row_end_nx = (r + 1 < m) ? a.rowptr[r + 2] : -1;
+    };
+    while (pos == row_end) flush();                 // leading empty rows (chunk 0 only)
+
+    int   cj_nx = 0;
+    float vj_nx = 0.f;
+    if (start + tl < end) { cj_nx = a.col[start + tl]; vj_nx = a.val[start + tl]; }
+    for (int base = start; base < end; base += 64) {
+      const int cnt = min(64, end - base);
+      const int cj = cj_nx;
+      const int vj = __builtin_bit_cast(int, vj_nx);
+      cj_nx = 0; vj_nx = 0.f;
+      if (base + 64 + tl < end) { cj_nx = a.col[base + 64 + tl]; vj_nx = a.val[base + 64 + tl]; }
+
+      float4 b[16];
+#define GCN_Q_GATHER(UU)                                                                         \
+      b[UU] = *reinterpret_cast<const float4*>(                                                  \
+          Bb + (size_t)(__umul24((unsigned)quad_bcast<UU>(cj), row_bytes) + foff));
+#define GCN_Q_VAL(UU) __builtin_bit_cast(float, quad_bcast<UU>(vj))
+      // entries past `cnt` carry col = 0, val = 0: they gather row 0 (valid memory) and are
+      // masked out below, never multiplied in
+      GCN_Q_GATHER(0) GCN_Q_GATHER(1) GCN_Q_GATHER(2) GCN_Q_GATHER(3)
+      GCN_Q_GATHER(4) GCN_Q_GATHER(5) GCN_Q_GATHER(6) GCN_Q_GATHER(7)
+      GCN_Q_GATHER(8) GCN_Q_GATHER(9) GCN_Q_GATHER(10) GCN_Q_GATHER(11)
+      GCN_Q_GATHER(12) GCN_Q_GATHER(13) GCN_Q_GATHER(14) GCN_Q_GATHER(15)
+      if (cnt == 64 && (row_end < 0 || row_end - pos >= 64)) {
+        // fast path: all 64 non-zeros belong to the current row
+#define GCN_Q_FMA(UU)                                                                            \
+        { const float v = GCN_Q_VAL(UU);                                                         \
+          acc.x = fmaf(v, b[UU].x, acc.x); acc.y = fmaf(v, b[UU].y, acc.y);                      \
+          acc.z = fmaf(v, b[UU].z, acc.z); acc.w = fmaf(v, b[UU].w, acc.w); }
+        GCN_Q_FMA(0) GCN_Q_FMA(1) GCN_Q_FMA(2) GCN_Q_FMA(3)
+        GCN_Q_FMA(4) GCN_Q_FMA(5) GCN_Q_FMA(6) GCN_Q_FMA(7)
+        GCN_Q_FMA(8) GCN_Q_FMA(9) GCN_Q_FMA(10) GCN_Q_FMA(11)
+        GCN_Q_FMA(12) GCN_Q_FMA(13) GCN_Q_FMA(14) GCN_Q_FMA(15)
+#undef GCN_Q_FMA
+        pos += 64;
+        while (pos == row_end) flush();
+      } else {
+        // rows end inside this block (or it is the ragged last block): one pass over the 16 steps
+        // per row segment [q0, q1) of the block, each lane adding only the products of its own
+        // non-zeros that lie in the segment (masked on the product, so a NaN/Inf in a feature row
+        // never leaks into a row of A that does not reference it)
+        int q0 = 0;
+        while (true) {
+          const int q1 = row_end < 0 ? cnt : min(cnt, row_end - base);
+          const unsigned lo = (unsigned)(q0 - sub), len = (unsigned)(q1 - q0);
+#define GCN_Q_SEG(UU)                                                                            \
+          { const bool in = (unsigned)(UU * 4) - lo < len;                                       \
+            const float v = GCN_Q_VAL(UU);                                                       \
+            acc.x = in ? fmaf(v, b[UU].x, acc.x) : acc.x; acc.y = in ? fmaf(v, b[UU].y, acc.y) : acc.y; \
+            acc.z = in ? fmaf(v, b[UU].z, acc.z) : acc.z; acc.w = in ? fmaf(v, b[UU].w, acc.w) : acc.w; }
+          GCN_Q_SEG(0) GCN_Q_SEG(1) GCN_Q_SEG(2) GCN_Q_SEG(3)
+          GCN_Q_SEG(4) GCN_Q_SEG(5) GCN_Q_SEG(6) GCN_Q_SEG(7)
+          GCN_Q_SEG(8) GCN_Q_SEG(9) GCN_Q_SEG(10) GCN_Q_SEG(11)
+          GCN_Q_SEG(12) GCN_Q_SEG(13) GCN_Q_SEG(14) GCN_Q_SEG(15)
+#undef GCN_Q_SEG
+          pos = base + q1;
+          if (pos != row_end) break;                // the row goes on past this block
+          while (pos == row_end) flush();           // row complete (+ any empty rows after it)
+          q0 = q1;
+          if (q0 >= cnt) break;
+        }
+      }
+#undef GCN_Q_GATHER
+#undef GCN_Q_VAL
+    }
+
+    if (last_flush != end) {                        // the row piece that sticks out of the chunk
+      const float4 t = quad_reduce(acc);
+      const int slot = head ? 2 * c : 2 * c + 1;
+      if (writer) *reinterpret_cast<float4*>(a.P + (size_t)slot * kk + fcol) = t;
+    }
+  }
+}
+
+bool spmm_quad_eligible(const SpmmArgs& a) {
+  const uintptr_t al = (uintptr_t)a.B | (uintptr_t)a.C | (uintptr_t)a.P | (uintptr_t)a.bias;
+  return a.k % 4 == 0 && (al & 15) == 0 && a.n < (1 << 24) && a.k * 4 < (1 << 24) &&
+         (unsigned long long)a.n * (unsigned long long)a.k * 4ull < 0xFFFFFFF0ull;
+}
+
+hipError_t launch_spmm_quad(const SpmmArgs& a, int nblocks, bool epi, hipStream_t s) {
+  const int tiles = (a.k + 63) / 64;
+  for (int t = 0; t < tiles; ++t) {
+#define GCN_QUAD_ARGS a.rowptr, a.col, a.val, a.B, a.C, a.P, a.chunk_row, a.bias, a.nnz_dev, \
+                      a.relu, a.nchunks, a.T, a.m, a.nnz, a.k, t, a.accumulate
+    if (epi) spmm_quad_kernel<true><<<dim3(nblocks), dim3(256), 0, s>>>(GCN_QUAD_ARGS);
+    else     spmm_quad_kernel<false><<<dim3(nblocks), dim3(256), 0, s>>>(GCN_QUAD_ARGS);
+#undef GCN_QUAD_ARGS
+  }
+  return hipGetLastError();
+}
+
+}  // namespace gcn
