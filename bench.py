@@ -92,6 +92,9 @@ def main():
     ap.add_argument("--force-shard", action="store_true",
                     help="debug: run the row-sharded pipelined path even with one rank (no collective)")
     ap.add_argument("--chunk", type=int, default=0, help="debug: chunk size in non-zeros (0 = automatic)")
+    ap.add_argument("--gather-width", type=int, default=-1,
+                    help="debug: non-zeros per gather instruction of the 64-column kernel (0 auto, 1, 4)")
+    ap.add_argument("--blocks-per-cu", type=int, default=0, help="debug: persistent-grid blocks per CU (1..8)")
     ap.add_argument("--sim-world", type=int, default=0,
                     help="debug: on ONE GPU, time rank 0's row block of a W-way partition (compute only, "
                          "no collective) — a rehearsal of the per-rank work at N = W, not a metric")
@@ -149,10 +152,13 @@ def main():
         pipe = PipelinedAggregation(shard, k, dev, plane_cols=64)
         pipe.load(H)
         if world > 1 or sim:
-            # 6 of 8 blocks per CU: the persistent SpMM grid leaves 8 wave slots per CU free so that the
-            # RCCL all-gather kernel runs BESIDE the next plane's SpMM instead of queueing behind it
-            # (costs 2 % of SpMM speed on one GPU, profiles/r01_sweep_blocks_per_cu.txt)
-            shard.local.set_blocks_per_cu(6)
+            # 3 blocks (12 waves) per CU: the four-per-gather kernel holds 108 VGPRs, so 4 blocks per CU
+            # is all that fits; a persistent grid of 3 leaves a wave slot and ~170 VGPRs per SIMD free so
+            # that the RCCL all-gather kernel runs BESIDE the next plane's SpMM instead of queueing
+            # behind it.  Rank-0 share of an 8-way partition, compute only (profiles/r01f_sim8_quad.log):
+            # 0.553 ms at 3 blocks/CU vs 0.527 ms at 8 (= 2 rounds of 4) vs 0.572 ms for the
+            # one-per-gather kernel at 6 blocks/CU.
+            shard.local.set_blocks_per_cu(3)
         launches_per_step = len(pipe.widths)
 
         def step():                       # layer l+1 consumes the all-gathered output of layer l
@@ -173,6 +179,11 @@ def main():
             pipe.load(H)
         del rowptr, col, val
         torch.cuda.empty_cache()
+
+    if args.gather_width >= 0:
+        local_adj.set_gather_width(args.gather_width)
+    if args.blocks_per_cu > 0:
+        local_adj.set_blocks_per_cu(args.blocks_per_cu)
 
     def barrier():
         if world > 1:
@@ -197,7 +208,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # ---- roofline of the dominant kernel (spmm_chunk_kernel), this rank's launches ---------
+    # ---- roofline of the dominant kernel (the plan's main kernel), this rank's launches ---------
     # (N = 1: one timed interval per SpMM = all column passes of the main kernel; N > 1: one per
     #  64-column plane SpMM of this rank's row block)
     kp = k if not sharded else min(k, 64)                 # columns per timed SpMM
@@ -206,7 +217,6 @@ def main():
     kavg = spmm_avg / passes                              # per LAUNCH, what rocprofv3 --stats averages
     balg = algorithmic_bytes(local_m, local_nnz, kp) / passes
     achieved = balg / kavg if kavg > 0 else 0.0
-    vec = min(4, max(1, kp // passes // 64))
     traffic = pmc_traffic(args.graph, k, passes) if not sharded and args.scale == 1.0 else None
 
     if rank == 0:
@@ -232,7 +242,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": f"gcn::spmm_chunk_kernel<{vec}, {({1: 32, 2: 8}).get(vec, 4)}, false, {'true' if vec == 1 else 'false'}>",
+                "kernel": local_adj.main_kernel(kp),
                 "slices": local_adj.num_slices,
                 "achieved": round(achieved / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK, 4),

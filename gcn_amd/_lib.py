@@ -32,7 +32,9 @@ SIGNATURES = {
     "gcn_spmm_csr_f32_bias_relu": (ctypes.c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i32, _c_i32, _c_p]),
     "gcn_spmm_plan_set_tile_cols": (ctypes.c_int, [_c_p, _c_i32]),
     "gcn_spmm_plan_set_blocks_per_cu": (ctypes.c_int, [_c_p, _c_i32]),
+    "gcn_spmm_plan_set_gather_width": (ctypes.c_int, [_c_p, _c_i32]),
     "gcn_spmm_plan_num_passes": (_c_i32, [_c_p, _c_i32]),
+    "gcn_spmm_plan_main_kernel": (ctypes.c_int, [_c_p, _c_i32, _c_i32, ctypes.c_char_p, _c_i32]),
     "gcn_spmm_plan_enable_slicing": (ctypes.c_int, [_c_p, _c_p, _c_p, _c_p, _c_i32, _c_p]),
     "gcn_spmm_plan_num_slices": (_c_i32, [_c_p]),
     "gcn_spmm_plan_enable_panels": (ctypes.c_int, [_c_p, _c_p, _c_p, _c_p, _c_i32, _c_p]),

@@ -28,7 +28,8 @@ struct gcn_spmm_plan {
   std::vector<hipEvent_t> ev;   // 2 per recorded launch
   int prof_cap, prof_n;
   int tile_cols;                // 0 = auto
-  int blocks_per_cu;            // persistent grid: blocks of 4 waves per CU (default 8 = all 32 wave slots)
+  int gather_width;             // non-zeros per gather instruction of the 64-column kernel: 0 auto, 1, 4
+  int blocks_per_cu;            // grid size: blocks of 4 waves per CU (default 32: oversubscribed, see header)
   // XCD-aware column slicing (slicing.hip): slice-major copy of the matrix with S*m virtual rows
   int S;                        // 0 = off
   int* vrowptr;                 // [S*m+1]
@@ -91,6 +92,12 @@ int auto_tile_cols(long long n, int k) {
   if (n * 256 <= budget) return 64;
   if (n * 512 <= budget && k > 128) return 128;
   return 0;                                      // widest tile k allows (<= 256 columns)
+}
+
+// smallest k the sliced path is used for (development knob GCN_AMD_SLICE_MIN_K)
+static int slice_min_k() {
+  static const int v = [] { const char* e = std::getenv("GCN_AMD_SLICE_MIN_K"); return e ? std::atoi(e) : 33; }();
+  return v;
 }
 
 // Number of column slices for the XCD-aware slicing (slicing.hip), 0 = do not slice.
@@ -169,7 +176,8 @@ int gcn_spmm_plan_create(gcn_spmm_plan_t** out, const int32_t* rowptr_dev, int32
   p->chunk_row = nullptr; p->ws = nullptr; p->ws_bytes = 0; p->cu_count = cu;
   p->prof_cap = p->prof_n = 0;
   p->tile_cols = 0;
-  p->blocks_per_cu = 8;
+  p->blocks_per_cu = 32;
+  p->gather_width = 0;
   (void)hipGetDevice(&p->device);
   if (p->nchunks > 0) {
     if (hipMalloc((void**)&p->chunk_row, sizeof(int) * (size_t)p->nchunks) != hipSuccess) {
@@ -230,8 +238,7 @@ int gcn_spmm_csr_f32_bias_relu(gcn_spmm_plan_t* p, const int32_t* rowptr, const 
   // narrow feature widths (k <= 32, the GCN hidden/class sizes) gather 128 B or less per
   // non-zero: there the extra partial rows cost more than the L2 hits buy (measured 2.12 vs
   // 2.02 ms at k = 32), so the sliced copy is used for k > 32 only
-  static const int slice_min_k = [] { const char* v = std::getenv("GCN_AMD_SLICE_MIN_K"); return v ? std::atoi(v) : 33; }();
-  const bool sliced = p->S > 0 && p->nnz > 0 && k >= slice_min_k;
+  const bool sliced = p->S > 0 && p->nnz > 0 && k >= slice_min_k();
   if (p->panel_R > 0 && p->nnz > 0 && k > 32) {
     // A = A_in + A_out: the staged part from LDS (raw sums into C), then the rest accumulated by the
     // chunk kernel, which also carries the epilogue
@@ -257,11 +264,13 @@ int gcn_spmm_csr_f32_bias_relu(gcn_spmm_plan_t* p, const int32_t* rowptr, const 
     a.T = p->pout_T; a.nnz = p->pout_nnz; a.accumulate = 1;
     a.tile_cols = p->tile_cols ? p->tile_cols : auto_tile_cols(p->n, k);
     a.blocks_per_cu = p->blocks_per_cu;
+    a.gather_width = p->gather_width;
     a.ev_start = nullptr; a.ev_stop = ev1;
     return gcn::launch_spmm(a, p->cu_count, st) == hipSuccess ? GCN_OK : GCN_ERR_HIP;
   }
   a.tile_cols = p->tile_cols ? p->tile_cols : (sliced ? 64 : auto_tile_cols(p->n, k));
   a.blocks_per_cu = p->blocks_per_cu;
+  a.gather_width = p->gather_width;
   if (p->prof_cap > 0 && p->prof_n < p->prof_cap) {
     a.ev_start = p->ev[2 * p->prof_n];
     a.ev_stop = p->ev[2 * p->prof_n + 1];
@@ -406,8 +415,14 @@ int gcn_spmm_plan_set_tile_cols(gcn_spmm_plan_t* p, int32_t cols) {
   return GCN_OK;
 }
 
+int gcn_spmm_plan_set_gather_width(gcn_spmm_plan_t* p, int32_t nz_per_gather) {
+  if (!p || (nz_per_gather != 0 && nz_per_gather != 1 && nz_per_gather != 4)) return GCN_ERR_INVALID_ARG;
+  p->gather_width = nz_per_gather;
+  return GCN_OK;
+}
+
 int gcn_spmm_plan_set_blocks_per_cu(gcn_spmm_plan_t* p, int32_t blocks) {
-  if (!p || blocks < 1 || blocks > 8) return GCN_ERR_INVALID_ARG;
+  if (!p || blocks < 1 || blocks > 64) return GCN_ERR_INVALID_ARG;
   p->blocks_per_cu = blocks;
   return GCN_OK;
 }
@@ -418,6 +433,20 @@ int32_t gcn_spmm_plan_num_passes(const gcn_spmm_plan_t* p, int32_t k) {
   const int tile = p->tile_cols ? p->tile_cols : (p->S > 0 && k > 32 ? 64 : auto_tile_cols(p->n, k));
   const int vec = gcn::pick_vec(k, tile, nullptr, nullptr, nullptr);   // 16-B aligned operands
   return (k + 64 * vec - 1) / (64 * vec);
+}
+
+int gcn_spmm_plan_main_kernel(const gcn_spmm_plan_t* p, int32_t k, int32_t epilogue, char* buf, int32_t buflen) {
+  if (!p || k <= 0 || !buf || buflen <= 0) return GCN_ERR_INVALID_ARG;
+  if (p->panel_R > 0 && k > 32) { snprintf(buf, (size_t)buflen, "gcn::spmm_panel_in_kernel"); return GCN_OK; }
+  gcn::SpmmArgs a{};
+  const bool sliced = p->S > 0 && p->nnz > 0 && k >= slice_min_k();
+  a.k = k; a.n = p->n; a.m = sliced ? p->S * p->m : p->m;
+  a.nchunks_grid = p->nchunks;
+  a.relu = epilogue && !sliced ? 1 : 0;               // sliced: the epilogue runs in the slice reduction
+  a.tile_cols = p->tile_cols ? p->tile_cols : (sliced ? 64 : auto_tile_cols(p->n, k));
+  a.gather_width = p->gather_width;
+  gcn::describe_main_kernel(a, buf, (size_t)buflen);
+  return GCN_OK;
 }
 
 int gcn_spmm_profile_begin(gcn_spmm_plan_t* p, int32_t capacity) {

@@ -28,8 +28,12 @@ struct SpmmArgs {
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
   int tile_cols = 0;       // feature-column tile per pass: 0 auto, else 64 / 128 / 256
   int accumulate = 0;      // 1: C += A*B (C already holds another part of the product); epilogue after the add
-  int blocks_per_cu = 8;   // persistent-grid size: 256-thread blocks per CU (1..8); < 8 leaves
-                           // wave slots free for a concurrent kernel (the RCCL all-gather)
+  int gather_width = 0;    // 64-column tile: non-zeros per gather instruction, 0 auto (4 when eligible), 1, 4
+  int blocks_per_cu = 32;  // grid size in 256-thread blocks per CU (1..64).  Up to 8 (4 for the 108-VGPR
+                           // quad kernel) are resident; more = later blocks start as earlier ones end, i.e.
+                           // the hardware dispatcher balances the load (Reddit-shaped, k=128: 3.96 ms at 8,
+                           // 3.68 ms at 32).  Less than the resident count leaves wave slots and registers
+                           // free for a concurrent kernel (the RCCL all-gather).
 };
 
 hipError_t launch_plan_chunk_rows(const int* rowptr, int m, int T, int nchunks,
@@ -38,6 +42,7 @@ hipError_t launch_spmm(const SpmmArgs& a, int cu_count, hipStream_t s);
 hipError_t launch_gather_rows(float* dst, const float* src, const int* idx, int nrows, int k,
                               hipStream_t s);
 int pick_vec(int k, int tile_cols, const void* B, const void* C, const void* P);
+void describe_main_kernel(const SpmmArgs& a, char* buf, size_t len);
 
 // spmm_narrow.hip — k <= 32: several non-zeros per gather instruction
 hipError_t launch_spmm_narrow(const SpmmArgs& a, int nblocks, bool epi, hipStream_t s);

@@ -24,6 +24,7 @@
 // non-zero = 8 + 4k.  MFMA is deliberately not used: fp32 MFMA
 // peak equals the fp32 VALU peak on gfx950 and the contraction is a gather.
 #include <hip/hip_runtime.h>
+#include <stdio.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include "spmm_kernels.h"
@@ -397,9 +398,10 @@ hipError_t launch_spmm(const SpmmArgs& a, int cu_count, hipStream_t s) {
     spmm_empty_kernel<<<nb, 256, 0, s>>>(a.C, a.bias, a.relu, total, a.k);
     return hipGetLastError();
   }
-  // persistent grid: up to 8 blocks of 4 waves per CU, multiple of 8 blocks (XCDs)
+  // grid: blocks_per_cu blocks of 4 waves per CU (chunks strided over the waves of an XCD), a multiple
+  // of 8 blocks (XCDs); the default 32 oversubscribes the CUs on purpose (spmm_kernels.h)
   int nblocks = (ng + 3) / 4;
-  const int cap = cu_count * (a.blocks_per_cu > 0 && a.blocks_per_cu < 8 ? a.blocks_per_cu : 8);
+  const int cap = cu_count * (a.blocks_per_cu > 0 && a.blocks_per_cu <= 64 ? a.blocks_per_cu : 32);
   if (nblocks > cap) nblocks = cap;
   nblocks = (nblocks + 7) & ~7;
   hipError_t e;
@@ -414,7 +416,7 @@ hipError_t launch_spmm(const SpmmArgs& a, int cu_count, hipStream_t s) {
     case 2:  e = launch_main<2, 8>(a, nblocks, epi, s); break;
     default: {
       static const bool quad_on = [] { const char* v = getenv("GCN_AMD_QUAD"); return !v || v[0] != '0'; }();
-      if (quad_on && spmm_quad_eligible(a)) { e = launch_spmm_quad(a, nblocks, epi, s); break; }
+      if (quad_on && a.gather_width != 1 && spmm_quad_eligible(a)) { e = launch_spmm_quad(a, nblocks, epi, s); break; }
       // gathers in flight per wave for the 64-column tile (development knob GCN_AMD_U1;
       // measured on the sliced Reddit-shaped case, whole SpMM: U = 4 / 8 / 16 / 32 ->
       // 5.16 / 4.33 / 4.18 / 4.09 ms; 52 VGPRs at U = 32, still 8 waves per SIMD)
@@ -437,6 +439,32 @@ hipError_t launch_spmm(const SpmmArgs& a, int cu_count, hipStream_t s) {
     e = hipGetLastError();
   }
   return e;
+}
+
+// Name (as rocprofv3 prints it) of the main kernel launch_spmm picks for these arguments; mirrors the
+// selection above.  Used by gcn_spmm_plan_main_kernel so that a benchmark reports the kernel that runs.
+void describe_main_kernel(const SpmmArgs& a, char* buf, size_t len) {
+  const bool epi = (a.bias != nullptr) || a.relu;
+  const char* e = epi ? "true" : "false";
+  static const bool narrow_on = [] { const char* v = getenv("GCN_AMD_NARROW"); return !v || v[0] != '0'; }();
+  static const bool quad_on = [] { const char* v = getenv("GCN_AMD_QUAD"); return !v || v[0] != '0'; }();
+  static const int u1 = [] { const char* v = getenv("GCN_AMD_U1"); return v ? atoi(v) : 32; }();
+  const bool buf32 = (unsigned long long)a.n * (unsigned long long)a.k * 4ull < 0xFFFFFFF0ull;
+  if (a.nchunks_grid == 0) { snprintf(buf, len, "gcn::spmm_empty_kernel"); return; }
+  if (a.k <= 16 && narrow_on) {
+    if (a.k > 8 && buf32 && a.n < (1 << 24)) snprintf(buf, len, "gcn::spmm_narrow16_dpp_kernel<%s>", e);
+    else {
+      const int g = a.k <= 4 ? 4 : (a.k <= 8 ? 8 : 16);
+      snprintf(buf, len, "gcn::spmm_narrow_kernel<%d, %d, %s, %s>", g, g, e, buf32 ? "true" : "false");
+    }
+    return;
+  }
+  const int vec = pick_vec(a.k, a.tile_cols, a.B, a.C, a.P);
+  if (vec == 4) { snprintf(buf, len, "gcn::spmm_chunk_kernel<4, 4, %s, false>", e); return; }
+  if (vec == 2) { snprintf(buf, len, "gcn::spmm_chunk_kernel<2, 8, %s, false>", e); return; }
+  if (quad_on && a.gather_width != 1 && spmm_quad_eligible(a)) { snprintf(buf, len, "gcn::spmm_quad_kernel<%s>", e); return; }
+  const int u = (u1 == 16 || u1 == 8 || u1 == 4) ? u1 : 32;
+  snprintf(buf, len, "gcn::spmm_chunk_kernel<1, %d, %s, %s>", u, e, buf32 ? "true" : "false");
 }
 
 hipError_t launch_gather_rows(float* dst, const float* src, const int* idx, int nrows, int k,

@@ -107,8 +107,14 @@ class CsrAdjacency:
         """Feature-column tile per kernel pass (0 auto, 64, 128, 256)."""
         _lib.check(_lib.load().gcn_spmm_plan_set_tile_cols(self.plan, int(cols)), "gcn_spmm_plan_set_tile_cols")
 
+    def set_gather_width(self, nz_per_gather):
+        """Non-zeros per gather instruction of the 64-column kernel: 0 auto, 1 or 4."""
+        _lib.check(_lib.load().gcn_spmm_plan_set_gather_width(self.plan, int(nz_per_gather)),
+                   "gcn_spmm_plan_set_gather_width")
+
     def set_blocks_per_cu(self, blocks):
-        """Persistent-grid size (1..8 blocks of 4 waves per CU); < 8 leaves room for a concurrent kernel."""
+        """Main-kernel grid in blocks of 4 waves per CU (1..64, default 32 = oversubscribed); below the
+        resident count (8, or 4 for the four-per-gather kernel) it leaves room for a concurrent kernel."""
         _lib.check(_lib.load().gcn_spmm_plan_set_blocks_per_cu(self.plan, int(blocks)),
                    "gcn_spmm_plan_set_blocks_per_cu")
 
@@ -141,6 +147,13 @@ class CsrAdjacency:
     def num_passes(self, k):
         """main-kernel launches (column passes) one k-wide SpMM issues"""
         return int(_lib.load().gcn_spmm_plan_num_passes(self.plan, int(k)))
+
+    def main_kernel(self, k, epilogue=False):
+        """name of the main kernel a k-wide SpMM on this plan launches (as rocprofv3 prints it)"""
+        buf = ctypes.create_string_buffer(128)
+        _lib.check(_lib.load().gcn_spmm_plan_main_kernel(self.plan, int(k), int(bool(epilogue)), buf, 128),
+                   "gcn_spmm_plan_main_kernel")
+        return buf.value.decode()
 
     def profile_begin(self, capacity):
         """Record HIP-event pairs around the main kernel of the next `capacity` launches."""

@@ -89,12 +89,24 @@ int gcn_spmm_csr_f32_bias_relu(gcn_spmm_plan_t* plan,
  * SpMM runs as ceil(k/tile) back-to-back passes, each gathering only its column slice of B
  * (smaller per-pass working set -> more of it stays in L2 / Infinity Cache). */
 int gcn_spmm_plan_set_tile_cols(gcn_spmm_plan_t* plan, int32_t cols);
-/* Size of the persistent grid: 256-thread blocks per CU, 1..8 (default 8 = all 32 wave slots of a
- * CU).  A smaller value leaves wave slots free so that a kernel on another stream — the RCCL
- * all-gather of the multi-GPU path — can run beside the SpMM instead of behind it. */
+/* Grid size of the main kernel in 256-thread blocks per CU, 1..64 (default 32).  At most 8 blocks
+ * (4 for the four-per-gather kernel) are resident on a CU; the default oversubscribes on purpose so
+ * that the hardware dispatcher hands out the remaining blocks as earlier ones finish (load balance:
+ * 3.96 -> 3.68 ms on the Reddit-shaped graph).  A value below the resident count leaves wave slots
+ * and registers free so that a kernel on another stream — the RCCL all-gather of the multi-GPU
+ * path — can run beside the SpMM instead of behind it. */
 int gcn_spmm_plan_set_blocks_per_cu(gcn_spmm_plan_t* plan, int32_t blocks);
+/* Non-zeros per gather instruction of the 64-column-tile kernel: 0 = automatic (4 — 16 lanes x 16 bytes
+ * per feature row, spmm_quad.hip — whenever k % 4 == 0, operands are 16-byte aligned, n < 2^24 and
+ * n*k*4 < 4 GiB; else 1), 1 = always the one-row-per-instruction kernel (52 VGPRs: leaves more
+ * room for a concurrent kernel), 4 = as 0.  Any other value: GCN_ERR_INVALID_ARG. */
+int gcn_spmm_plan_set_gather_width(gcn_spmm_plan_t* plan, int32_t nz_per_gather);
 /* number of main-kernel launches (column passes) one k-wide SpMM issues with the current tile */
 int32_t gcn_spmm_plan_num_passes(const gcn_spmm_plan_t* plan, int32_t k);
+/* name (as rocprofv3 --kernel-trace prints it, without the argument list) of the main kernel a
+ * k-wide SpMM on this plan launches with the current settings and 16-byte aligned operands;
+ * epilogue != 0: the bias/ReLU variant.  For benchmarks that report which kernel they timed. */
+int gcn_spmm_plan_main_kernel(const gcn_spmm_plan_t* plan, int32_t k, int32_t epilogue, char* buf, int32_t buflen);
 
 /* XCD-aware column slicing (optional, off by default).  Builds, on the device, a slice-major copy
  * of the matrix (`slices` equal column ranges; virtual row s*m+r = the part of row r in slice s)

@@ -102,18 +102,69 @@ def test_edge_cases_empty_and_tiny():
     assert rel_err(C, Cref) <= TOL
 
 
-def test_nan_inf_do_not_leak_between_rows():
-    """a row of B holding Inf/NaN only poisons the output rows that reference it"""
+@pytest.mark.parametrize("k", [4, 8, 16, 33, 64, 128, 256])
+def test_nan_inf_do_not_leak_between_rows(k):
+    """a row of B holding Inf/NaN only poisons the output rows that reference it — for every kernel
+    family (narrow k <= 16, one-non-zero-per-gather, four-per-gather).  Row 0 is the row the kernels'
+    padding lanes gather (ragged last block), row 317 an ordinary one."""
     m = n = 600
-    rowptr, col, val = random_csr(m, n, 6000, seed=11)
+    rowptr, col, val = random_csr(m, n, 6003, seed=11)          # nnz % 64 != 0: ragged last block
     rng = np.random.default_rng(5)
-    B = rng.standard_normal((n, 128)).astype(np.float32)
+    B = rng.standard_normal((n, k)).astype(np.float32)
     B[0, :] = np.inf
+    B[317, :] = np.nan
     adj = _adj(rowptr, col, val, m, n)
     C = adj.matmul_raw(torch.from_numpy(B).to(_dev())).cpu().numpy()
-    touches0 = np.array([0 in col[rowptr[r]:rowptr[r + 1]] for r in range(m)])
-    assert np.all(np.isfinite(C[~touches0]))
-    assert rel_err(C[~touches0], oracle_spmm(rowptr, col, val, np.where(np.isfinite(B), B, 0))[~touches0]) <= TOL
+    touched = np.array([bool(np.isin([0, 317], col[rowptr[r]:rowptr[r + 1]]).any()) for r in range(m)])
+    assert touched.any() and (~touched).any()
+    assert np.all(np.isfinite(C[~touched]))
+    assert not np.any(np.isfinite(C[touched]).all(axis=1))      # and the rows that do reference them show it
+    assert rel_err(C[~touched], oracle_spmm(rowptr, col, val, np.where(np.isfinite(B), B, 0))[~touched]) <= TOL
+
+
+@pytest.mark.parametrize("width", [1, 4])
+@pytest.mark.parametrize("k", [20, 64, 128, 200])
+def test_parity_gather_widths(width, k):
+    """the 64-column tile with one and with four non-zeros per gather instruction
+    (gcn_spmm_plan_set_gather_width), on ragged input: empty rows, hub rows, rows of 1..5 non-zeros,
+    rows ending on block and chunk boundaries; plain and with the fused epilogue"""
+    m, n = 3000, 5000
+    rowptr, col, val = random_csr(m, n, 30000, seed=k + width, empty_rows=0.2,
+                                  long_rows=[(0, 0), (5, 4097), (6, 64), (7, 128), (8, 1), (9, 2), (10, 3),
+                                             (11, 63), (12, 65), (2000, 2500), (m - 1, 0), (m - 2, 5)])
+    rng = np.random.default_rng(k)
+    B = rng.standard_normal((n, k)).astype(np.float32)
+    bias = rng.standard_normal(k).astype(np.float32)
+    for chunk in (0, 64, 256):
+        adj = _adj(rowptr, col, val, m, n, chunk_nnz=chunk)
+        adj.set_gather_width(width)
+        assert ("quad" in adj.main_kernel(k)) == (width == 4)
+        Bd = torch.from_numpy(B).to(_dev())
+        C = adj.matmul_raw(Bd).cpu().numpy()
+        Cref = oracle_spmm(rowptr, col, val, B)
+        assert rel_err(C, Cref) <= TOL
+        assert np.all(C[np.diff(rowptr) == 0] == 0.0)
+        Ce = adj.matmul_raw(Bd, bias=torch.from_numpy(bias).to(_dev()), relu=True).cpu().numpy()
+        assert rel_err(Ce, np.maximum(Cref + bias, 0)) <= TOL
+
+
+def test_main_kernel_families_are_selected_as_documented():
+    """which kernel runs for which feature width (gcn_spmm_plan_main_kernel), so that the parity
+    tests above are known to cover every family"""
+    m = n = 1000
+    rowptr, col, val = random_csr(m, n, 20000, seed=1)
+    adj = _adj(rowptr, col, val, m, n)
+    assert adj.main_kernel(4).startswith("gcn::spmm_narrow_kernel<4,")
+    assert adj.main_kernel(16) == "gcn::spmm_narrow16_dpp_kernel<false>"
+    assert adj.main_kernel(17).startswith("gcn::spmm_chunk_kernel<1,")
+    assert adj.main_kernel(32) == "gcn::spmm_quad_kernel<false>"
+    assert adj.main_kernel(128) == "gcn::spmm_quad_kernel<false>"
+    assert adj.main_kernel(128, epilogue=True) == "gcn::spmm_quad_kernel<true>"
+    assert adj.main_kernel(130).startswith("gcn::spmm_chunk_kernel<1,")      # k % 4 != 0
+    adj.set_tile_cols(256)
+    assert adj.main_kernel(256).startswith("gcn::spmm_chunk_kernel<4,")
+    adj.set_tile_cols(128)
+    assert adj.main_kernel(256).startswith("gcn::spmm_chunk_kernel<2,")
 
 
 def test_deterministic_and_geometry_independent():
