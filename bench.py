@@ -109,12 +109,21 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a HIP device (no CPU fallback for the product path)")
+    # rehearsal on a ONE-GPU box (not a metric): GCN_AMD_BENCH_REHEARSAL=1 puts every rank on cuda:0 and
+    # swaps RCCL (which refuses two ranks on one device) for gloo — same partition, same pipeline, same
+    # kernels, same checks; only the transport differs
+    rehearsal = os.environ.get("GCN_AMD_BENCH_REHEARSAL", "0") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
-        os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")   # collective kernels ahead of compute in the HW queues
-        dist.init_process_group("nccl", device_id=dev)          # nccl == RCCL on ROCm
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")   # collective kernels ahead of compute in the HW queues
+            dist.init_process_group("nccl", device_id=dev)          # nccl == RCCL on ROCm
 
     # ---- inputs (same seeds on every rank → identical graph everywhere) -------------------
     rowptr, col, val, n = graphgen.make_graph(args.graph, device=dev, seed=1, scale=args.scale)
@@ -231,7 +240,7 @@ def main():
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
+            "data": "synthetic" if not rehearsal else "synthetic; REHEARSAL (all ranks on one GPU, gloo transport) - not a metric",
             "config": {
                 "workload": f"{args.graph}-shaped R-MAT graph, n={n}, nnz={nnz} (incl. self-loops), "
                             f"feat={k}, fp32, no reorder; step = C = Â·H"

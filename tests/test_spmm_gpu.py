@@ -343,7 +343,7 @@ def test_full_size_reddit_shape_properties():
 
 # --- the N>1 building blocks on the real kernel (the collective itself is covered by the gloo
 # --- tests in test_dist.py; one box has one GPU) ------------------------------------------------
-def test_row_sharded_blocks_reproduce_the_single_gpu_result_bitwise():
+def test_row_sharded_blocks_reproduce_the_single_gpu_result():
     from gcn_amd.dist import PipelinedAggregation, RowShardedAdjacency
     n, k, d = 6000, 128, _dev()
     rowptr, col, val = sym_norm_graph(n, 150000, seed=9)
