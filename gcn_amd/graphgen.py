@@ -133,6 +133,59 @@ def make_rmat(scale, edge_factor=16, abcd=(0.57, 0.19, 0.19, 0.05), device="cpu"
     return rowptr, col, val, n
 
 
+def make_rmat_row_block(n, directed_edges, world, rank, abcd=(0.57, 0.19, 0.19, 0.05), device="cpu", seed=4,
+                        batch=1 << 26):
+    """Row block `rank` of `world` (contiguous, equal row counts) of a graph too large to materialise
+    whole on one device (BASELINE config 4, papers100M-shaped: n = 111 059 956, 1.616 G directed
+    samples): R-MAT samples folded to n, vertex labels randomly permuted, symmetrised, de-duplicated,
+    self-loops added, Â = D^-1/2 (A+I) D^-1/2.  The sample stream is regenerated once per row block
+    (same seed → same graph) so that only one block's entries are ever resident; the degrees of ALL
+    vertices (needed for the values) come out of those passes.
+    → (rowptr[int32, rows+1], col[int32], val[fp32], n, row_lo, row_hi) with GLOBAL column indices."""
+    device = torch.device(device)
+    rows_per = (n + world - 1) // world
+    pgen = torch.Generator(device=device)
+    pgen.manual_seed(seed + 1000)
+    perm = torch.randperm(n, generator=pgen, device=device)
+    deg = torch.zeros(n, dtype=torch.int64, device=device)
+    mine = None
+    for b in range(world):
+        lo, hi = b * rows_per, min(n, (b + 1) * rows_per)
+        gen = torch.Generator(device=device)
+        gen.manual_seed(seed)                                  # the same sample stream for every block
+        parts, done = [], 0
+        while done < directed_edges:
+            cnt = min(batch, directed_edges - done)
+            u, v = _rmat_pairs(n, cnt, abcd, gen, device)
+            u, v = perm[u], perm[v]
+            ok = u != v
+            u, v = u[ok], v[ok]
+            for r, c in ((u, v), (v, u)):                      # symmetrise; keep the entries of this block's rows
+                m = (r >= lo) & (r < hi)
+                parts.append((r[m] - lo) * n + c[m])
+            done += cnt
+            del u, v, ok
+            if len(parts) >= 16:                               # bound the backlog: fold it into one unique'd part
+                parts = [torch.unique(torch.cat(parts))]
+        keys = torch.unique(torch.cat(parts))
+        del parts
+        deg[lo:hi] = torch.bincount(keys // n, minlength=hi - lo) + 1          # + the self-loop
+        if b == rank:
+            mine = keys
+        del keys
+    lo, hi = rank * rows_per, min(n, (rank + 1) * rows_per)
+    loops = torch.arange(lo, hi, dtype=torch.int64, device=device)
+    keys = torch.sort(torch.cat([mine, (loops - lo) * n + loops])).values
+    del mine, loops
+    rows, cols = keys // n, keys % n
+    del keys
+    rowptr = torch.zeros(hi - lo + 1, dtype=torch.int64, device=device)
+    rowptr[1:] = torch.cumsum(torch.bincount(rows, minlength=hi - lo), 0)
+    dinv = deg.to(torch.float64).pow(-0.5)
+    val = (dinv[rows + lo] * dinv[cols]).to(torch.float32)
+    return rowptr.to(torch.int32), cols.to(torch.int32), val, n, lo, hi
+
+
 def random_features(n, k, seed=2, device="cpu"):
     """B ~ N(0,1) fp32 [n x k] (the reference standard-scales features, profiling_gcn.py:31-35)."""
     gen = torch.Generator(device=torch.device(device))

@@ -29,3 +29,29 @@ def test_small_reddit_shaped_graph_is_valid_and_deterministic():
 def test_cora_shape_matches_survey_numbers():
     rp, ci, va, n = graphgen.make_graph("cora", device="cpu", seed=0)
     assert n == 2485 and int(ci.numel()) == 12623     # nnz = 2*5069 + 2485
+
+
+def test_row_blocks_of_a_graph_too_large_to_hold_whole_tile_one_symmetric_normalised_matrix():
+    """make_rmat_row_block (BASELINE config 4 stand-in): the row blocks, generated independently from
+    the same seed, stack to one symmetric Â = D^-1/2 (A+I) D^-1/2 with sorted, distinct columns."""
+    import numpy as np
+    import scipy.sparse as sp
+    n, samples, world = 3000, 40000, 4
+    mats, seen = [], 0
+    for r in range(world):
+        rp, ci, va, nn, lo, hi = graphgen.make_rmat_row_block(n, samples, world, r, device="cpu", seed=4, batch=1 << 13)
+        assert nn == n and lo == seen and rp.dtype == torch.int32 and ci.dtype == torch.int32 and va.dtype == torch.float32
+        seen = hi
+        rows = np.repeat(np.arange(hi - lo), np.diff(rp.numpy()))
+        key = rows.astype(np.int64) * n + ci.numpy()
+        assert np.all(np.diff(key) > 0)                       # sorted within rows, no duplicates
+        mats.append(sp.csr_matrix((va.numpy(), ci.numpy(), rp.numpy()), shape=(hi - lo, n)))
+    assert seen == n
+    A = sp.vstack(mats).tocsr()
+    assert abs(A - A.T).max() == 0.0 and np.all(A.diagonal() > 0)
+    d = np.asarray((A != 0).sum(1)).ravel()
+    coo = A.tocoo()
+    assert np.abs(coo.data - 1.0 / np.sqrt(d[coo.row] * d[coo.col])).max() < 1e-7
+    # deterministic
+    again = graphgen.make_rmat_row_block(n, samples, world, 1, device="cpu", seed=4, batch=1 << 13)
+    assert torch.equal(again[1], graphgen.make_rmat_row_block(n, samples, world, 1, device="cpu", seed=4, batch=1 << 13)[1])

@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""tools/papers100m_rank_share.py — BASELINE config 4 (papers100M-shaped, 8 GPUs) on ONE GPU: the
+row block one rank of an 8-way partition owns, generated at full scale (n = 111 059 956 vertices,
+1.616 G directed R-MAT samples, symmetrised ≈ 3.3 G non-zeros in the whole graph) and multiplied with
+the FULL feature matrix (n x 128 fp32 = 57 GB — what the rank holds after the all-gather).  Compute
+only: the RCCL all-gather of the layer output cannot be exercised on one device.  Not the judged
+metric; a stated stand-in for the per-rank work of config 4.
+
+    python tools/papers100m_rank_share.py [--scale 1.0] [--world 8] [--rank 0] [--k 128]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import gcn_amd                      # noqa: E402
+from gcn_amd import graphgen        # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--scale", type=float, default=1.0)
+    ap.add_argument("--world", type=int, default=8)
+    ap.add_argument("--rank", type=int, default=0)
+    ap.add_argument("--k", type=int, default=128)
+    ap.add_argument("--iters", type=int, default=5)
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    n = int(111059956 * args.scale)
+    samples = int(1615685872 * args.scale)
+    t0 = time.time()
+    rowptr, col, val, n, lo, hi = graphgen.make_rmat_row_block(n, samples, args.world, args.rank, device=dev, seed=4)
+    torch.cuda.synchronize()
+    m, nnz, k = hi - lo, int(col.numel()), args.k
+    print(f"# block rows [{lo}, {hi}) of n={n}: m={m} nnz={nnz} mean_deg={nnz / m:.1f} "
+          f"generated in {time.time() - t0:.1f} s", flush=True)
+    B = graphgen.random_features(n, k, seed=2, device=dev)
+    C = torch.empty((m, k), device=dev)
+    adj = gcn_amd.CsrAdjacency(rowptr, col, val, (m, n), symmetric=False)
+    for _ in range(2):
+        adj.matmul_raw(B, out=C)
+    torch.cuda.synchronize()
+    passes = adj.num_passes(k)
+    adj.profile_begin(args.iters * passes)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(args.iters):
+        adj.matmul_raw(B, out=C)
+    e1.record()
+    torch.cuda.synchronize()
+    kms = adj.profile_end()
+    step = e0.elapsed_time(e1) / args.iters
+    # sampled check against fp64 (2 000 rows)
+    g = torch.Generator(device=dev)
+    g.manual_seed(0)
+    rows = torch.randint(0, m, (2000,), generator=g, device=dev)
+    err, ref_max = 0.0, 0.0
+    rp = rowptr.long()
+    for r in rows.tolist()[:2000]:
+        s, e = int(rp[r]), int(rp[r + 1])
+        ref = (val[s:e].double()[:, None] * B[col[s:e].long()].double()).sum(0)
+        err = max(err, float((C[r].double() - ref).abs().max()))
+        ref_max = max(ref_max, float(ref.abs().max()))
+    balg = nnz * (8 + 4 * k) + (m + 1) * 4 + m * k * 4
+    line = {
+        "config": "papers100M-shaped, rank share of an 8-way row partition on ONE GPU (compute only, no all-gather)",
+        "n": n, "rows": m, "nnz_block": nnz, "k": k, "world": args.world, "rank": args.rank, "scale": args.scale,
+        "kernel": adj.main_kernel(k), "passes": passes, "slices": adj.num_slices,
+        "ms_per_spmm": round(step, 3), "main_kernel_ms_per_spmm": round(sum(kms) / args.iters, 3),
+        "GFLOP/s": round(2.0 * nnz * k / step / 1e6, 1),
+        "algorithmic_GBps": round(balg / step / 1e6, 1), "frac_of_8TBps": round(balg / step / 1e-3 / 8e12, 4),
+        "features_GB": round(n * k * 4 / 1e9, 1),
+        "sampled_rel_err_vs_fp64": err / max(ref_max, 1e-30),
+    }
+    print(json.dumps(line), flush=True)
+
+
+if __name__ == "__main__":
+    main()
