@@ -44,6 +44,9 @@ SIGNATURES = {
     "gcn_spmm_profile_end": (ctypes.c_int, [_c_p, _c_p, _c_p]),
     "gcn_spmm_csr_f32_oneshot": (ctypes.c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_i32, _c_i32, _c_i32, _c_i32, _c_p]),
     "gcn_gather_rows_f32": (ctypes.c_int, [_c_p, _c_p, _c_p, _c_i32, _c_i32, _c_p]),
+    "gcn_order_deg_device": (ctypes.c_int, [_c_p, _c_p, _c_i32, _c_i32, _c_i32, _c_i32, _c_p, _c_p]),
+    "gcn_order_rcm_device": (ctypes.c_int, [_c_p, _c_p, _c_i32, _c_i32, _c_p, _c_p, _c_p]),
+    "gcn_csr_apply_rank_device": (ctypes.c_int, [_c_p, _c_p, _c_p, _c_p, _c_i32, _c_i32, _c_p, _c_p, _c_p, _c_p, _c_p]),
     "gcn_order_deg": (ctypes.c_int, [_c_p, _c_p, _c_i32, _c_i32, _c_i32, _c_i32, _c_p]),
     "gcn_order_rcm": (ctypes.c_int, [_c_p, _c_p, _c_i32, _c_i32, _c_i32, _c_p]),
     "gcn_order_gorder": (ctypes.c_int, [_c_p, _c_p, _c_i32, _c_i32, _c_i32, _c_p]),

@@ -555,6 +555,38 @@ int gcn_order_rcm(const int32_t* rowptr, const int32_t* col, int32_t n, int32_t 
   return GCN_OK;
 }
 
+int gcn_order_deg_device(const int32_t* rowptr_dev, const int32_t* col_dev, int32_t n, int32_t nnz,
+                         int32_t which, int32_t desc, int32_t* rank_out_dev, void* stream) {
+  if (n < 0 || nnz < 0 || which < 0 || which > 2 || (n > 0 && (!rowptr_dev || !rank_out_dev)) || (nnz > 0 && !col_dev))
+    return GCN_ERR_INVALID_ARG;
+  return gcn::device_order_deg(rowptr_dev, col_dev, n, nnz, which, desc ? 1 : 0, rank_out_dev,
+                               (hipStream_t)stream) == hipSuccess ? GCN_OK : GCN_ERR_HIP;
+}
+
+int gcn_order_rcm_device(const int32_t* rowptr_dev, const int32_t* col_dev, int32_t n, int32_t nnz,
+                         int32_t* rank_out_dev, int32_t* bfs_levels_out, void* stream) {
+  if (n < 0 || nnz < 0 || (n > 0 && (!rowptr_dev || !rank_out_dev)) || (nnz > 0 && !col_dev))
+    return GCN_ERR_INVALID_ARG;
+  int levels = 0;
+  const hipError_t e = gcn::device_order_rcm(rowptr_dev, col_dev, n, nnz, rank_out_dev, &levels, (hipStream_t)stream);
+  if (bfs_levels_out) *bfs_levels_out = levels;
+  return e == hipSuccess ? GCN_OK : GCN_ERR_HIP;
+}
+
+int gcn_csr_apply_rank_device(const int32_t* rowptr_dev, const int32_t* col_dev, const float* val_dev,
+                              const int32_t* rank_dev, int32_t n, int32_t nnz, int32_t* out_rowptr_dev,
+                              int32_t* out_col_dev, float* out_val_dev, int32_t* vomp_out_dev, void* stream) {
+  if (n < 0 || nnz < 0) return GCN_ERR_INVALID_ARG;
+  if (n > 0 && (!rowptr_dev || !rank_dev || !out_rowptr_dev || !vomp_out_dev)) return GCN_ERR_INVALID_ARG;
+  if (nnz > 0 && (!col_dev || !val_dev || !out_col_dev || !out_val_dev)) return GCN_ERR_INVALID_ARG;
+  if (out_col_dev == col_dev || out_val_dev == val_dev || out_rowptr_dev == rowptr_dev) return GCN_ERR_INVALID_ARG;
+  int bad = 0;
+  const hipError_t e = gcn::device_csr_apply_rank(rowptr_dev, col_dev, val_dev, rank_dev, n, nnz, out_rowptr_dev,
+                                                  out_col_dev, out_val_dev, vomp_out_dev, &bad, (hipStream_t)stream);
+  if (e != hipSuccess) return GCN_ERR_HIP;
+  return bad ? GCN_ERR_INVALID_ARG : GCN_OK;
+}
+
 int gcn_order_gorder(const int32_t* rowptr, const int32_t* col, int32_t n, int32_t nnz,
                      int32_t window, int64_t* rank_out) {
   if (!rank_out || window < 1 || !csr_ok(rowptr, col, n, nnz)) return GCN_ERR_INVALID_ARG;

@@ -62,6 +62,15 @@ hipError_t launch_panel_in(const int* in_rowptr, const int* in_off, const float*
                            hipStream_t s);
 hipError_t launch_panel_epilogue(float* C, const float* bias, int relu, int m, int k, hipStream_t s);
 
+// reorder_device.hip — degree / RCM orderings and the CSR rewrite on the device (same integers as reorder.cpp)
+hipError_t device_order_deg(const int* rowptr, const int* col, int n, int nnz, int which, int desc,
+                            int* rank_out, hipStream_t st);
+hipError_t device_order_rcm(const int* rowptr, const int* col, int n, int nnz, int* rank_out,
+                            int* levels_out, hipStream_t st);
+hipError_t device_csr_apply_rank(const int* rowptr, const int* col, const float* val, const int* rank, int n,
+                                 int nnz, int* out_rowptr, int* out_col, float* out_val, int* vomp_out,
+                                 int* bad_rank_host, hipStream_t st);
+
 // slicing.hip
 hipError_t build_sliced_csr(const int* rowptr, const int* col, const float* val, int m, int n,
                             int nnz, int S, int* vrowptr, int* vcol, float* vval,

@@ -99,6 +99,14 @@ def order_deg_device(rowptr, col, which="total", desc=True):
     is bit-identical to the host version whatever the sort algorithm."""
     import torch
     n = rowptr.numel() - 1
+    if rowptr.is_cuda:                      # the library's device kernels (reorder_device.hip)
+        rp, ci = rowptr.to(torch.int32).contiguous(), col.to(torch.int32).contiguous()
+        rank = torch.empty(n, dtype=torch.int32, device=rowptr.device)
+        _lib.check(_lib.load().gcn_order_deg_device(
+            ctypes.c_void_p(rp.data_ptr()), ctypes.c_void_p(ci.data_ptr()), n, int(ci.numel()),
+            {"total": 0, "out": 1, "in": 2}[which], int(bool(desc)), ctypes.c_void_p(rank.data_ptr()),
+            ctypes.c_void_p(torch.cuda.current_stream(rowptr.device).cuda_stream)), "gcn_order_deg_device")
+        return rank.to(torch.int64)
     out_deg = (rowptr[1:] - rowptr[:-1]).to(torch.int64)
     in_deg = torch.bincount(col.to(torch.int64), minlength=n)
     deg = {"total": out_deg + in_deg, "out": out_deg, "in": in_deg}[which]
@@ -108,3 +116,44 @@ def order_deg_device(rowptr, col, which="total", desc=True):
     rank = torch.empty(n, dtype=torch.int64, device=deg.device)
     rank[order] = ids
     return rank
+
+
+def order_rcm_device(rowptr, col, return_levels=False):
+    """order_rcm on the GPU (reorder_device.hip): CUDA int32 CSR tensors in, int64
+    rank[old]=new on the same device out — the same integers as `order_rcm(..., directed=False)`
+    (and `directed=True` when the pattern is symmetric, as GCN adjacencies are)."""
+    import torch
+    if not rowptr.is_cuda:
+        raise _lib.GcnAmdError("order_rcm_device needs CUDA/HIP tensors (the host version is order_rcm)")
+    n = rowptr.numel() - 1
+    rp, ci = rowptr.to(torch.int32).contiguous(), col.to(torch.int32).contiguous()
+    rank = torch.empty(n, dtype=torch.int32, device=rowptr.device)
+    levels = ctypes.c_int32(0)
+    _lib.check(_lib.load().gcn_order_rcm_device(
+        ctypes.c_void_p(rp.data_ptr()), ctypes.c_void_p(ci.data_ptr()), n, int(ci.numel()),
+        ctypes.c_void_p(rank.data_ptr()), ctypes.cast(ctypes.byref(levels), ctypes.c_void_p),
+        ctypes.c_void_p(torch.cuda.current_stream(rowptr.device).cuda_stream)), "gcn_order_rcm_device")
+    rank = rank.to(torch.int64)
+    return (rank, int(levels.value)) if return_levels else rank
+
+
+def apply_rank_device(rowptr, col, vals, rank):
+    """CSR rewrite under rank[old]=new on the GPU (renumber.cu:190-217 semantics: rows and columns
+    relabelled, every row's columns ascending, values carried along).
+    → (rowptr', col', vals', vomp) with vomp[new]=old, all on the input device."""
+    import torch
+    if not rowptr.is_cuda:
+        raise _lib.GcnAmdError("apply_rank_device needs CUDA/HIP tensors (the host version is apply_rank)")
+    n, nnz = rowptr.numel() - 1, int(col.numel())
+    rp, ci = rowptr.to(torch.int32).contiguous(), col.to(torch.int32).contiguous()
+    va, rk = vals.to(torch.float32).contiguous(), rank.to(torch.int32).contiguous()
+    d = rowptr.device
+    o_rp = torch.empty(n + 1, dtype=torch.int32, device=d)
+    o_ci = torch.empty(nnz, dtype=torch.int32, device=d)
+    o_va = torch.empty(nnz, dtype=torch.float32, device=d)
+    vomp = torch.empty(n, dtype=torch.int32, device=d)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    _lib.check(_lib.load().gcn_csr_apply_rank_device(p(rp), p(ci), p(va), p(rk), n, nnz, p(o_rp), p(o_ci), p(o_va),
+                                                     p(vomp), ctypes.c_void_p(torch.cuda.current_stream(d).cuda_stream)),
+               "gcn_csr_apply_rank_device")
+    return o_rp, o_ci, o_va, vomp

@@ -178,6 +178,26 @@ int gcn_csr_apply_rank(int32_t* rowptr, int32_t* col, float* vals, int32_t n, in
                        const int64_t* rank, int32_t* vomp_out);
 
 /* ------------------------------------------------------------------------- */
+/* (1d) the same orderings ON THE DEVICE: device pointers in,   */
+/*      int32 rank_out[old] = new on the device, identical integers to the    */
+/*      host versions above.  order_rcm_device works on the symmetrised       */
+/*      pattern A ∪ Aᵀ (= gcn_order_rcm with directed = 0; for symmetric      */
+/*      patterns also directed = 1): component labelling + multi-source       */
+/*      level-synchronous BFS whose per-level radix sort reproduces the       */
+/*      serial queue order of algo_bfs.cu:11-39 exactly (reorder_device.hip). */
+/*      csr_apply_rank_device = gcn_csr_apply_rank out of place (outputs must */
+/*      not alias inputs); GCN_ERR_INVALID_ARG if rank is not a permutation.  */
+/*      All three synchronise the stream before returning.                    */
+/* ------------------------------------------------------------------------- */
+int gcn_order_deg_device(const int32_t* rowptr_dev, const int32_t* col_dev, int32_t n, int32_t nnz,
+                         int32_t which, int32_t desc, int32_t* rank_out_dev, void* stream);
+int gcn_order_rcm_device(const int32_t* rowptr_dev, const int32_t* col_dev, int32_t n, int32_t nnz,
+                         int32_t* rank_out_dev, int32_t* bfs_levels_out /* host, may be NULL */, void* stream);
+int gcn_csr_apply_rank_device(const int32_t* rowptr_dev, const int32_t* col_dev, const float* val_dev,
+                              const int32_t* rank_dev, int32_t n, int32_t nnz, int32_t* out_rowptr_dev,
+                              int32_t* out_col_dev, float* out_val_dev, int32_t* vomp_out_dev, void* stream);
+
+/* ------------------------------------------------------------------------- */
 /* (2) DROP-IN symbols — identical names and argument lists to the reference.  */
 /* ------------------------------------------------------------------------- */
 
