@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """tools/profiling_gcn.py — the reference's driver (profiling_gcn.py:85-170, run.sh) on gcn_amd:
 
-    python tools/profiling_gcn.py -g reddit -k 128 -i 100 [--order rabbit|gorder|dfs|none] [--fuse]
+    python tools/profiling_gcn.py -g reddit -k 128 -i 100 [--order rabbit|gorder|dfs|rcm|deg|none] [--fuse]
 
 Loads ./dataset/<graph>/ in GraphSAINT format when it exists (profiling_gcn.py:22-37); otherwise
 (no dataset ships offline) trains on the shape-matched synthetic stand-in with random features
@@ -26,7 +26,7 @@ def main():
     ap.add_argument("-g", "--graph", default="reddit")
     ap.add_argument("-k", "--hidden", type=int, default=128)
     ap.add_argument("-i", "--train-iters", dest="train_iters", type=int, default=100)
-    ap.add_argument("--order", default="none", choices=["none", "dfs", "gorder", "rabbit"])
+    ap.add_argument("--order", default="none", choices=["none", "dfs", "gorder", "rabbit", "rcm", "deg"])
     ap.add_argument("--fuse", action="store_true", help="bias + ReLU in the SpMM epilogue")
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--nfeat", type=int, default=602)       # Reddit's input width
