@@ -288,7 +288,9 @@ bool slide_window(const Adj& b, LazyBuckets& h, u64 incoming, u64 outgoing) {
 
   // parents of exactly one of the two vertices (sorted-list symmetric difference),
   // hubs (out-degree > sqrt n) skipped
-  std::vector<u64> leaving, entering;
+  static thread_local std::vector<u64> leaving, entering;       // scratch, reused across the n calls
+  leaving.clear();
+  entering.clear();
   while (true) {
     bool take_new;
     if (op >= oe) {
@@ -422,11 +424,81 @@ std::vector<u64> order_dfs(const Csr& g) {
   return rank;
 }
 
+// Neighbour -> merged edge count, one per vertex.  The reference keeps a std::map<int,int> here
+// (renumber.cu:331-336) and its observable behaviour depends on the key ORDER in exactly one place:
+// the merge target is the first maximum of dQ when the map is scanned in key order with a strict '>'
+// (renumber.cu:14-20, :419-425) — i.e. the maximum, ties to the smallest key.  Everything else
+// (weight accumulation, erasing the merged vertex from its neighbours' maps) is order-independent, so
+// an open-addressing table with that tie rule gives identical results without the per-node
+// allocations and pointer chasing that dominate the reference's 29.5 s per 3.4 M non-zeros.
+class NbrTable {
+ public:
+  int size() const { return live_; }
+  template <typename F> void for_each(F&& f) const {
+    for (size_t i = 0; i < key_.size(); ++i)
+      if (key_[i] >= 0) f(key_[i], val_[i]);
+  }
+  // w[k] += dv (inserting k with 0 first, like std::map::operator[])
+  void add(int k, int dv) {
+    if ((used_ + 1) * 10 > (int)key_.size() * 7) grow();
+    const size_t mask = key_.size() - 1;
+    size_t i = hash(k) & mask, first_free = (size_t)-1;
+    while (key_[i] != kEmpty) {
+      if (key_[i] == k) { val_[i] += dv; return; }
+      if (key_[i] == kDead && first_free == (size_t)-1) first_free = i;
+      i = (i + 1) & mask;
+    }
+    if (first_free != (size_t)-1) i = first_free; else ++used_;
+    key_[i] = k; val_[i] = dv; ++live_;
+  }
+  // value of k, or -1 when absent (weights are >= 1)
+  int find(int k) const {
+    if (key_.empty()) return -1;
+    const size_t mask = key_.size() - 1;
+    size_t i = hash(k) & mask;
+    while (key_[i] != kEmpty) {
+      if (key_[i] == k) return val_[i];
+      i = (i + 1) & mask;
+    }
+    return -1;
+  }
+  void erase(int k) {
+    if (key_.empty()) return;
+    const size_t mask = key_.size() - 1;
+    size_t i = hash(k) & mask;
+    while (key_[i] != kEmpty) {
+      if (key_[i] == k) { key_[i] = kDead; --live_; return; }
+      i = (i + 1) & mask;
+    }
+  }
+  void release() { std::vector<int>().swap(key_); std::vector<int>().swap(val_); live_ = used_ = 0; }
+
+ private:
+  static constexpr int kEmpty = -1, kDead = -2;
+  static size_t hash(int k) { return (size_t)((unsigned)k * 2654435761u) >> 7; }
+  void grow() {
+    size_t cap = 8;
+    while (cap * 7 < (size_t)(live_ + 1) * 20) cap *= 2;      // <= 35 % full after a rebuild
+    std::vector<int> ok(cap, kEmpty), ov(cap, 0);
+    ok.swap(key_); ov.swap(val_);
+    live_ = used_ = 0;
+    for (size_t i = 0; i < ok.size(); ++i)
+      if (ok[i] >= 0) {
+        const size_t mask = key_.size() - 1;
+        size_t j = hash(ok[i]) & mask;
+        while (key_[j] != kEmpty) j = (j + 1) & mask;
+        key_[j] = ok[i]; val_[j] = ov[i]; ++live_; ++used_;
+      }
+  }
+  std::vector<int> key_, val_;
+  int live_ = 0, used_ = 0;     // live entries; slots ever occupied (live + tombstones)
+};
+
 // renumber.cu:319-520 (opt_iterative = true, hub grouping off, shyness 1).
 std::vector<int32_t> order_rabbit_vomp(const Csr& g, bool verbose) {
   const int n = (int)g.n;
   struct Vtx {
-    std::map<int, int> w;   // neighbour -> merged edge count (unit weights)
+    NbrTable w;             // neighbour -> merged edge count (unit weights)
     int deg = 0;
     int round = 0;
     int tree = -1;          // dendrogram node id owned by this vertex, -1 = merged away
@@ -444,10 +516,10 @@ std::vector<int32_t> order_rabbit_vomp(const Csr& g, bool verbose) {
     for (int32_t e = g.rowptr[v]; e < g.rowptr[v + 1]; ++e) {
       const int d = g.col[e];
       if (d == v) continue;
-      V[v].w[d] = 1;
-      V[d].w[v] = 1;
+      if (V[v].w.find(d) < 0) V[v].w.add(d, 1);          // map[d] = 1: insert-or-assign, weights stay 1
+      if (V[d].w.find(v) < 0) V[d].w.add(v, 1);
     }
-    V[v].deg = (int)V[v].w.size();
+    V[v].deg = V[v].w.size();
     n_edges += V[v].deg;
     V[v].tree = v;
     cur[v] = v;
@@ -465,23 +537,24 @@ std::vector<int32_t> order_rabbit_vomp(const Csr& g, bool verbose) {
       double best = -1;
       int v = -1;
       const double dv_2m = uo.deg * two_m_inv;
-      for (auto [d, w] : uo.w) {                       // key order, strict > (renumber.cu:14-20,423)
+      uo.w.for_each([&](int d, int w) {                  // first maximum in key order = max, ties to the smallest key
         const double dq = w - V[d].deg * dv_2m;
-        if (dq > best) { best = dq; v = d; }
-      }
+        if (dq > best || (dq == best && v >= 0 && d < v)) { best = dq; v = d; }
+      });
       if (best <= 0) continue;
       Vtx& vo = V[v];
       vo.deg += uo.deg;
-      for (auto [d, w] : uo.w) {
-        if (d == v) continue;
-        vo.w[d] += w;
+      uo.w.for_each([&](int d, int w) {                  // (no self keys: neither vo.w nor V[d].w is uo.w)
+        if (d == v) return;
+        vo.w.add(d, w);
         auto& dm = V[d].w;
-        auto it = dm.find((int)u);
-        if (it == dm.end()) continue;
-        dm[v] += it->second;
+        const int back = dm.find((int)u);
+        if (back < 0) return;
+        dm.add(v, back);
         dm.erase((int)u);
-      }
+      });
       vo.w.erase((int)u);
+      uo.w.release();            // u is out of every neighbour's table (the relation stays symmetric): never read again
       lch[(size_t)n + u] = vo.tree;                    // (target's tree, merged tree)
       rch[(size_t)n + u] = uo.tree;
       uo.tree = -1;

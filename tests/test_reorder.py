@@ -59,6 +59,11 @@ def _graphs():
     A = sp.coo_matrix((np.ones(e), (u, v)), shape=(n, n)).tocsr(); A = (A + sp.eye(n)).tocsr()
     A.data[:] = rng.random(A.nnz) + 0.1; A.sort_indices()
     yield "directed_skewed", (A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.astype(np.float32))
+    # R-MAT, products-shaped degree skew (hub rows, many equal dQ candidates): the case where Rabbit's
+    # "first maximum in key order" tie rule and the equal-degree introsort permutation really matter
+    from gcn_amd import graphgen
+    rowptr, col, val, _ = graphgen.make_graph("products", device="cpu", seed=3, scale=0.006)
+    yield "rmat_products_shaped", (rowptr.numpy(), col.numpy(), val.numpy())
 
 
 @pytest.mark.skipif(not (os.path.exists(REF_SO) and os.path.exists(REF_ORD)),
