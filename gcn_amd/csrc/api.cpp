@@ -101,24 +101,26 @@ static int slice_min_k() {
 }
 
 // Number of column slices for the XCD-aware slicing (slicing.hip), 0 = do not slice.
-// Measured on MI355X (profiles/r01_sweep_slices_*.txt, Reddit-shaped graphs of 58 k .. 932 k
-// vertices, mean degree 493): the best S keeps one slice of the 64-column tile (n/S x 256 B) near
-// 4-8 MiB (the per-XCD L2 is 4 MiB) with at least ~16 non-zeros per virtual row; at mean degree
-// 51 (products-shaped) slicing loses (virtual rows of ~6 non-zeros, 8 partial rows per output row).
+// Measured on MI355X with the r01f kernels (profiles/r01f_sweep_slices_scales.log; Reddit-shaped graphs
+// of 14.5 k .. 1.86 M vertices, mean degree 493; whole SpMM, k = 128, best S in brackets):
+//   n = 14.5 k (64-column table 3.7 MB): slicing buys nothing;  29 k (7.5 MB): [2] 0.352 vs 0.394 ms
+//   unsliced;  58 k: [4] 0.84 vs 1.18;  116 k: [4/8] 1.76-1.80 vs 3.13;  233 k: [8] 3.62 vs 7.3;
+//   466 k: [8] 9.20 vs 15.7 (16: 9.84);  932 k: [8] 24.4 vs 32.3;  1.86 M: [8] 56.5 vs 62.5.
+// So: as many slices as bring one slice of the table (n/S x 256 B) down to the 4 MiB of an XCD's L2,
+// but never more than the 8 XCDs — beyond 8 every XCD walks several slices and the extra partial rows
+// (S*m*k floats written and re-read) cost more than the higher hit rate returns.  Needs >= 16
+// non-zeros per virtual row; at mean degree 51 (products-shaped) slicing loses and stays off.
 int auto_slices(long long m, long long n, long long nnz) {
   if (m <= 0 || nnz <= 0) return 0;
-  const long long per_row = nnz / m / 16;           // slices that still leave >= 16 nnz per virtual row
-  int s_deg = 1;
-  while (2LL * s_deg <= per_row) s_deg *= 2;
-  if (s_deg < 8) return 0;
-  const long long want = (n * 256 + (8LL << 20) - 1) / (8LL << 20);
-  int s_tab = 8;
-  while (s_tab < want) s_tab *= 2;
-  int S = s_tab < s_deg ? s_tab : s_deg;
-  if (S > 64) S = 64;
-  // the degree cap can leave slices far larger than any cache (huge n, moderate degree): then the
-  // partial rows cost traffic and buy no hits — stay unsliced
-  if (n * 256 / S > (32LL << 20)) return 0;
+  if (nnz / m < 128) return 0;                        // low degree: partial rows outweigh the hits
+  const long long table = n * 256;                    // bytes of one 64-column tile of B
+  if (table <= (4LL << 20)) return 0;                 // fits every L2 as it is
+  int S = 2;
+  while (S < 8 && table / S > (4LL << 20)) S *= 2;
+  while (S > 1 && nnz / m / S < 16) S /= 2;           // keep >= 16 non-zeros per virtual row
+  if (S < 2) return 0;
+  // slices far larger than any cache (huge n): the partial rows cost traffic and buy no hits
+  if (table / S > (64LL << 20)) return 0;
   return S;
 }
 

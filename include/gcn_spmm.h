@@ -114,7 +114,7 @@ int gcn_spmm_plan_main_kernel(const gcn_spmm_plan_t* plan, int32_t k, int32_t ep
  * then gathers from only ~slices/8 column slices of B, sized to stay in its 4 MiB L2, and a
  * reduction over slices (in slice order, deterministic) produces C.  Needs column-sorted rows
  * (GCN_ERR_INVALID_ARG otherwise); slices = 0/1 turns it off; slices = -1 picks the count from
- * (m, n, nnz) — off for low-degree graphs, 8..64 otherwise — and silently stays off for
+ * (m, n, nnz) — off for low-degree graphs and tables that fit an L2 anyway, 2..8 otherwise — and silently stays off for
  * unsorted rows.  The matrix passed here must be the
  * one the plan was created for.  Costs one extra copy of col/val plus slices*m*k floats. */
 int gcn_spmm_plan_enable_slicing(gcn_spmm_plan_t* plan, const int32_t* rowptr_dev,

@@ -115,8 +115,8 @@ def test_csr2tile_slice_major_packing_is_a_permutation_of_the_matrix():
     import torch
     from gcn_amd import dropin
     from util import sym_norm_graph
-    n = 800
-    rowptr, col, val = sym_norm_graph(n, 90000, seed=2)
+    n = 17000                                # 64-column table 4.35 MB > one 4 MiB L2 -> 2 slices (auto_slices)
+    rowptr, col, val = sym_norm_graph(n, 1200000, seed=2)
     nnz = len(col)
     assert nnz // n >= 128
     rng = np.random.default_rng(0)           # hand the rows over UNSORTED: csr2tile sorts them itself
@@ -127,7 +127,7 @@ def test_csr2tile_slice_major_packing_is_a_permutation_of_the_matrix():
     seg_rowPtr, segNzCV, segVoMap, tail, nxt, n_segs = dropin.csr2tile(
         torch.from_numpy(rowptr.copy()), torch.from_numpy(col_u), torch.from_numpy(val_u), n, n, nnz,
         torch.arange(n, dtype=torch.int32))
-    S, w = 8, (n + 7) // 8
+    S, w = 2, (n + 1) // 2
     vrp = seg_rowPtr.numpy()[: S * n + 1]
     assert vrp[0] == 0 and vrp[-1] == nnz and np.all(np.diff(vrp) >= 0)
     vcol = segNzCV[:nnz].numpy().view(np.int32)

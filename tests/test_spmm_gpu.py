@@ -412,8 +412,8 @@ def test_slicing_refuses_unsorted_rows():
 def test_dropin_pair_with_xcd_slicing_on_a_dense_graph():
     """mean degree >= 128: csr2tile packs the slice-major virtual CSR and flexspmm (which only
     sees device pointers, m, n, k, n_segs) recovers S, the chunk size and nnz by itself"""
-    n = 3000
-    rowptr, col, val = sym_norm_graph(n, 330000, seed=12)
+    n = 17000                                # 64-column table 4.35 MB > one 4 MiB L2 -> 2 slices (auto_slices)
+    rowptr, col, val = sym_norm_graph(n, 1200000, seed=12)
     nnz = len(col)
     assert nnz // n >= 128
     d = _dev()
@@ -421,7 +421,7 @@ def test_dropin_pair_with_xcd_slicing_on_a_dense_graph():
     out = dropin.csr2tile(t_rp, t_ci, t_va, n, n, nnz, torch.arange(n, dtype=torch.int32))
     seg_rowPtr, segNzCV, segVoMap, tail, nxt, n_segs = out
     # the packed row pointer is the virtual one: S*m rows, ends at nnz
-    S = 8
+    S = 2
     assert int(seg_rowPtr[S * n]) == nnz and int(seg_rowPtr[n]) < nnz
     dev = [t.to(d) for t in (seg_rowPtr, segNzCV, segVoMap, tail, nxt)]
     rng = np.random.default_rng(5)
