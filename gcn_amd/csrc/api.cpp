@@ -38,6 +38,8 @@ struct gcn_spmm_plan {
   int* vchunk_row;              // [nchunks] rows of the virtual CSR
   float* cv;                    // partial outputs [S*m x k], grow-only
   size_t cv_bytes;
+  float* bpad;                  // B re-laid with rows padded to whole 128-byte lines (odd k), grow-only
+  size_t bpad_bytes;
   // LDS-staged row panels (spmm_panel.hip): rows per panel, 0 = off; measured window coverage
   int panel_R;
   int* panel_w0;                // device [ceil(m / panel_R)]: first column of each panel's window
@@ -92,6 +94,46 @@ int auto_tile_cols(long long n, int k) {
   if (n * 256 <= budget) return 64;
   if (n * 512 <= budget && k > 128) return 128;
   return 0;                                      // widest tile k allows (<= 256 columns)
+}
+
+// re-lay B with rows padded to whole cache lines for k % 32 != 0 (development knob GCN_AMD_PAD_B=0: off)
+static bool pad_b_enabled() {
+  static const bool v = [] { const char* e = std::getenv("GCN_AMD_PAD_B"); return !e || e[0] != '0'; }();
+  return v;
+}
+
+// Expected 128-byte cache lines one gathered feature row costs, summed over its 64-column tiles, when B's
+// rows are `ld` floats apart (the row start offsets cycle through the multiples of gcd(4*ld, 128)).
+static double lines_per_row(int k, int ld) {
+  const long long row_bytes = 4LL * ld;
+  long long g = row_bytes % 128;
+  for (long long a = 128; g != 0;) { const long long t = a % g; a = g; g = t; if (g == 0) { g = a; break; } }
+  if (g == 0) g = 128;                                // row_bytes % 128 == 0: every row starts on a line
+  const int period = (int)(128 / g);
+  double total = 0;
+  for (int r = 0; r < period; ++r) {
+    const long long off = (r * row_bytes) % 128;
+    for (long long t0 = 0; t0 < 4LL * k; t0 += 256) {
+      const long long w = (4LL * k - t0) < 256 ? (4LL * k - t0) : 256;
+      const long long start = (off + t0) % 128;
+      total += (double)((start + w - 1) / 128 + 1);
+    }
+  }
+  return total / period;
+}
+
+// Row stride (floats) B is gathered with: k itself, or k rounded up to whole 128-byte lines when that
+// saves >= 15 % of the cache lines per gathered row and the re-laid table stays <= 768 MiB.  Measured
+// (profiles/r01f_sweep_padded_feature_rows.log, whole SpMM, unpadded -> padded): Reddit-shaped k = 20:
+// 2.19 -> 1.60 ms, 24: 2.26 -> 1.60, 47: 2.11 -> 2.00, 100: 4.43 -> 3.84, 172: 7.56 -> 5.73; no saving
+// by the model and none measured for k = 40, 48 (rows of 160 / 192 B never straddle more lines than
+// padded ones); products-shaped k = 47 (627 MB padded): 5.41 -> 4.86 ms, k = 100 (1.25 GB): 8.95 ->
+// 9.73 ms — past the Infinity Cache the larger table and the copy cost more than the lines save.
+static int padded_ldb(long long n, int k) {
+  if (k <= 16 || k % 32 == 0 || !pad_b_enabled()) return k;
+  const int ld = (k + 31) / 32 * 32;
+  if ((long long)sizeof(float) * n * ld > (768LL << 20)) return k;
+  return lines_per_row(k, k) >= 1.15 * lines_per_row(k, ld) ? ld : k;
 }
 
 // smallest k the sliced path is used for (development knob GCN_AMD_SLICE_MIN_K)
@@ -178,6 +220,7 @@ int gcn_spmm_plan_create(gcn_spmm_plan_t** out, const int32_t* rowptr_dev, int32
   p->chunk_row = nullptr; p->ws = nullptr; p->ws_bytes = 0; p->cu_count = cu;
   p->prof_cap = p->prof_n = 0;
   p->tile_cols = 0;
+  p->bpad = nullptr; p->bpad_bytes = 0;
   p->blocks_per_cu = 32;
   p->gather_width = 0;
   (void)hipGetDevice(&p->device);
@@ -203,6 +246,7 @@ int gcn_spmm_plan_destroy(gcn_spmm_plan_t* p) {
   if (p->vval) (void)hipFree(p->vval);
   if (p->vchunk_row) (void)hipFree(p->vchunk_row);
   if (p->cv) (void)hipFree(p->cv);
+  if (p->bpad) (void)hipFree(p->bpad);
   {
     void* ptrs[] = {p->panel_w0, p->pin_rowptr, p->pin_off, p->pin_val, p->pout_rowptr, p->pout_col,
                     p->pout_val, p->pout_chunk_row};
@@ -237,6 +281,25 @@ int gcn_spmm_csr_f32_bias_relu(gcn_spmm_plan_t* p, const int32_t* rowptr, const 
   a.chunk_row = p->chunk_row; a.bias = bias; a.relu = relu ? 1 : 0;
   a.nchunks = p->nchunks; a.T = p->T; a.m = p->m; a.nnz = p->nnz; a.k = k; a.n = p->n;
   a.nnz_dev = nullptr; a.nchunks_grid = p->nchunks;
+  // Feature rows that are not a whole number of 128-byte cache lines straddle lines: a gathered row
+  // then costs up to one extra L2 request per tile.  Where that matters (padded_ldb) B is first re-laid
+  // with its rows padded to the next multiple of 32 floats (one streaming copy, ~45 us for 233 k x 100)
+  // and gathered from there; C keeps the caller's layout.
+  if (const int ldb = padded_ldb(p->n, k); p->nnz > 0 && ldb != k) {
+    const size_t need = sizeof(float) * (size_t)p->n * (size_t)ldb;
+    {
+      std::lock_guard<std::mutex> lk(g_mu);
+      if (need > p->bpad_bytes) {
+        if (p->bpad) (void)hipFree(p->bpad);
+        p->bpad = nullptr; p->bpad_bytes = 0;
+        if (hipMalloc((void**)&p->bpad, need) != hipSuccess) return GCN_ERR_ALLOC;
+        p->bpad_bytes = need;
+      }
+    }
+    if (gcn::launch_pad_rows(p->bpad, B, p->n, k, ldb, (hipStream_t)stream) != hipSuccess) return GCN_ERR_HIP;
+    a.B = p->bpad;
+    a.ldb = ldb;
+  }
   // narrow feature widths (k <= 32, the GCN hidden/class sizes) gather 128 B or less per
   // non-zero: there the extra partial rows cost more than the L2 hits buy (measured 2.12 vs
   // 2.02 ms at k = 32), so the sliced copy is used for k > 32 only
@@ -447,6 +510,7 @@ int gcn_spmm_plan_main_kernel(const gcn_spmm_plan_t* p, int32_t k, int32_t epilo
   a.relu = epilogue && !sliced ? 1 : 0;               // sliced: the epilogue runs in the slice reduction
   a.tile_cols = p->tile_cols ? p->tile_cols : (sliced ? 64 : auto_tile_cols(p->n, k));
   a.gather_width = p->gather_width;
+  if (const int ldb = padded_ldb(p->n, k); ldb != k) a.ldb = ldb;
   gcn::describe_main_kernel(a, buf, (size_t)buflen);
   return GCN_OK;
 }

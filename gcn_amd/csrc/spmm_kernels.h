@@ -18,6 +18,7 @@ struct SpmmArgs {
   int relu;
   int nchunks, T, m, nnz, k;
   int n = 0x7fffffff;      // rows of B (columns of A); decides 32-bit buffer addressing
+  int ldb = 0;             // row stride of B in floats, 0 = k (api.cpp pads rows to 128-byte lines for odd k)
   // drop-in mode (flexspmm symbol): nnz is only known on the device (nnz_dev =
   // &rowptr[m]); the kernels then derive nchunks and the value pointer themselves
   // and the host sizes its grids with the upper bound nchunks_grid.
@@ -41,6 +42,8 @@ hipError_t launch_plan_chunk_rows(const int* rowptr, int m, int T, int nchunks,
 hipError_t launch_spmm(const SpmmArgs& a, int cu_count, hipStream_t s);
 hipError_t launch_gather_rows(float* dst, const float* src, const int* idx, int nrows, int k,
                               hipStream_t s);
+// dst[r, 0:k] = src[r, 0:k], dst[r, k:ld] = 0 for r < rows (dst row stride ld >= k)
+hipError_t launch_pad_rows(float* dst, const float* src, long long rows, int k, int ld, hipStream_t s);
 int pick_vec(int k, int tile_cols, const void* B, const void* C, const void* P);
 void describe_main_kernel(const SpmmArgs& a, char* buf, size_t len);
 
@@ -49,6 +52,7 @@ hipError_t launch_spmm_narrow(const SpmmArgs& a, int nblocks, bool epi, hipStrea
 
 // spmm_quad.hip — 64-column tile, four non-zeros per 16-byte-per-lane gather instruction
 bool spmm_quad_eligible(const SpmmArgs& a);
+int spmm_quad_lanes(int k);
 hipError_t launch_spmm_quad(const SpmmArgs& a, int nblocks, bool epi, hipStream_t s);
 
 // spmm_panel.hip — LDS-staged feature tiles per row panel (near-diagonal matrices)

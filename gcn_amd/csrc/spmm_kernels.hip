@@ -109,7 +109,7 @@ spmm_chunk_kernel(const int* __restrict__ g_rowptr, const int* __restrict__ g_co
                   float* __restrict__ g_C, float* __restrict__ g_P,
                   const int* __restrict__ g_chunk_row, const float* __restrict__ g_bias,
                   const int* __restrict__ g_nnz_dev,
-                  int relu, int nchunks, int T, int m, int nnz, int kk, int col_tile, int accumulate) {
+                  int relu, int nchunks, int T, int m, int nnz, int kk, int col_tile, int accumulate, int ldb) {
   // drop-in (flexspmm) mode: the host does not know nnz; it lives in rowptr[m] and
   // the values follow the column indices in one buffer (api.cpp, csr2tile layout)
   if (g_nnz_dev) {
@@ -146,7 +146,8 @@ spmm_chunk_kernel(const int* __restrict__ g_rowptr, const int* __restrict__ g_co
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(g_B), 0, 0xFFFFFFFFu, 0x00020000);
   const int voff = (active ? fcol : 0) * 4;
-  const unsigned row_bytes = (unsigned)a.k * 4u;
+  const unsigned row_bytes = (unsigned)ldb * 4u;     // B row stride (>= k: rows may be padded to 128-byte lines)
+  const size_t ldB = (size_t)ldb;
 
   float bias[VEC];
 #pragma unroll
@@ -219,7 +220,7 @@ spmm_chunk_kernel(const int* __restrict__ g_rowptr, const int* __restrict__ g_co
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const int cu = __builtin_amdgcn_readlane(cj, j + u);
-          gather_row<VEC, BUF>(Bl, rsrc, voff, cu, k, row_bytes, b[u]);
+          gather_row<VEC, BUF>(Bl, rsrc, voff, cu, ldB, row_bytes, b[u]);
         }
         if (row_end - pos >= U || row_end < 0) {
           // fast path: the current row does not end strictly inside this batch
@@ -249,7 +250,7 @@ spmm_chunk_kernel(const int* __restrict__ g_rowptr, const int* __restrict__ g_co
         const int cu = __builtin_amdgcn_readlane(cj, j);
         const float vu = __builtin_bit_cast(float,
             __builtin_amdgcn_readlane(__builtin_bit_cast(int, vj), j));
-        gather_row<VEC, BUF>(Bl, rsrc, voff, cu, k, row_bytes, b1);
+        gather_row<VEC, BUF>(Bl, rsrc, voff, cu, ldB, row_bytes, b1);
 #pragma unroll
         for (int i = 0; i < VEC; ++i) acc[i] = fmaf(vu, b1[i], acc[i]);
         ++pos;
@@ -356,9 +357,10 @@ static hipError_t launch_main(const SpmmArgs& a, int nblocks, bool epi, hipStrea
   const int tiles = (a.k + 64 * VEC - 1) / (64 * VEC);
   dim3 grid(nblocks), block(256);
 #define GCN_MAIN_ARGS a.rowptr, a.col, a.val, a.B, a.C, a.P, a.chunk_row, a.bias, a.nnz_dev, \
-                      a.relu, a.nchunks, a.T, a.m, a.nnz, a.k, t, a.accumulate
+                      a.relu, a.nchunks, a.T, a.m, a.nnz, a.k, t, a.accumulate, ldb
+  const int ldb = a.ldb > 0 ? a.ldb : a.k;
   // buffer addressing needs every byte offset into B to fit 32 bits
-  const bool buf = VEC == 1 && (unsigned long long)a.n * (unsigned long long)a.k * 4ull < 0xFFFFFFF0ull;
+  const bool buf = VEC == 1 && (unsigned long long)a.n * (unsigned long long)ldb * 4ull < 0xFFFFFFF0ull;
   for (int t = 0; t < tiles; ++t) {
     if constexpr (VEC == 1) {
       if (buf) {
@@ -387,6 +389,15 @@ int pick_vec(int k, int tile_cols, const void* B, const void* C, const void* P) 
   return 1;
 }
 
+// the quad kernel (spmm_quad.hip) runs whenever its layout applies: k % 4 == 0, 16-byte aligned operands,
+// 32-bit byte offsets; for k > 32 only where the 64-column tile is the chosen tile width
+static bool use_quad(const SpmmArgs& a) {
+  static const bool quad_on = [] { const char* v = getenv("GCN_AMD_QUAD"); return !v || v[0] != '0'; }();
+  static const int min_k = [] { const char* v = getenv("GCN_AMD_QUAD_MIN_K"); return v ? atoi(v) : 12; }();
+  if (!quad_on || a.gather_width == 1 || a.k < min_k || !spmm_quad_eligible(a)) return false;
+  return a.k <= 32 || pick_vec(a.k, a.tile_cols, a.B, a.C, a.P) == 1;
+}
+
 hipError_t launch_spmm(const SpmmArgs& a, int cu_count, hipStream_t s) {
   const bool epi = (a.bias != nullptr) || a.relu;
   if (a.m <= 0 || a.k <= 0) return hipSuccess;
@@ -407,16 +418,16 @@ hipError_t launch_spmm(const SpmmArgs& a, int cu_count, hipStream_t s) {
   hipError_t e;
   if (a.ev_start && (e = hipEventRecord(a.ev_start, s)) != hipSuccess) return e;
   static const bool narrow_on = [] { const char* v = getenv("GCN_AMD_NARROW"); return !v || v[0] != '0'; }();
-  // k <= 16: several non-zeros per gather instruction (spmm_narrow.hip).  k = 17..32 stays on the
-  // wide kernel: measured 1.67 ms (wide, 32 of 64 lanes) vs 2.94 ms (two non-zeros per instruction).
-  if (a.k <= 16 && narrow_on) {
+  if (use_quad(a)) {
+    // 16-byte-per-lane gathers, 4 (k > 16) or 16 (k <= 16) non-zeros per instruction (spmm_quad.hip)
+    e = launch_spmm_quad(a, nblocks, epi, s);
+  } else if (a.k <= 16 && narrow_on && (a.ldb == 0 || a.ldb == a.k)) {
+    // k <= 16 without the alignment the quad kernel needs: several non-zeros per 4-byte-per-lane gather
     e = launch_spmm_narrow(a, nblocks, epi, s);
   } else switch (pick_vec(a.k, a.tile_cols, a.B, a.C, a.P)) {
     case 4:  e = launch_main<4, 4>(a, nblocks, epi, s); break;
     case 2:  e = launch_main<2, 8>(a, nblocks, epi, s); break;
     default: {
-      static const bool quad_on = [] { const char* v = getenv("GCN_AMD_QUAD"); return !v || v[0] != '0'; }();
-      if (quad_on && a.gather_width != 1 && spmm_quad_eligible(a)) { e = launch_spmm_quad(a, nblocks, epi, s); break; }
       // gathers in flight per wave for the 64-column tile (development knob GCN_AMD_U1;
       // measured on the sliced Reddit-shaped case, whole SpMM: U = 4 / 8 / 16 / 32 ->
       // 5.16 / 4.33 / 4.18 / 4.09 ms; 52 VGPRs at U = 32, still 8 waves per SIMD)
@@ -447,11 +458,11 @@ void describe_main_kernel(const SpmmArgs& a, char* buf, size_t len) {
   const bool epi = (a.bias != nullptr) || a.relu;
   const char* e = epi ? "true" : "false";
   static const bool narrow_on = [] { const char* v = getenv("GCN_AMD_NARROW"); return !v || v[0] != '0'; }();
-  static const bool quad_on = [] { const char* v = getenv("GCN_AMD_QUAD"); return !v || v[0] != '0'; }();
   static const int u1 = [] { const char* v = getenv("GCN_AMD_U1"); return v ? atoi(v) : 32; }();
-  const bool buf32 = (unsigned long long)a.n * (unsigned long long)a.k * 4ull < 0xFFFFFFF0ull;
+  const bool buf32 = (unsigned long long)a.n * (unsigned long long)(a.ldb > 0 ? a.ldb : a.k) * 4ull < 0xFFFFFFF0ull;
   if (a.nchunks_grid == 0) { snprintf(buf, len, "gcn::spmm_empty_kernel"); return; }
-  if (a.k <= 16 && narrow_on) {
+  if (use_quad(a)) { snprintf(buf, len, "gcn::spmm_quad_kernel<%d, %s>", spmm_quad_lanes(a.k), e); return; }
+  if (a.k <= 16 && narrow_on && (a.ldb == 0 || a.ldb == a.k)) {
     if (a.k > 8 && buf32 && a.n < (1 << 24)) snprintf(buf, len, "gcn::spmm_narrow16_dpp_kernel<%s>", e);
     else {
       const int g = a.k <= 4 ? 4 : (a.k <= 8 ? 8 : 16);
@@ -462,9 +473,28 @@ void describe_main_kernel(const SpmmArgs& a, char* buf, size_t len) {
   const int vec = pick_vec(a.k, a.tile_cols, a.B, a.C, a.P);
   if (vec == 4) { snprintf(buf, len, "gcn::spmm_chunk_kernel<4, 4, %s, false>", e); return; }
   if (vec == 2) { snprintf(buf, len, "gcn::spmm_chunk_kernel<2, 8, %s, false>", e); return; }
-  if (quad_on && a.gather_width != 1 && spmm_quad_eligible(a)) { snprintf(buf, len, "gcn::spmm_quad_kernel<%s>", e); return; }
   const int u = (u1 == 16 || u1 == 8 || u1 == 4) ? u1 : 32;
   snprintf(buf, len, "gcn::spmm_chunk_kernel<1, %d, %s, %s>", u, e, buf32 ? "true" : "false");
+}
+
+// dst[r, 0:k] = src[r, 0:k], dst[r, k:ld] = 0: feature rows re-laid on whole 128-byte lines
+__global__ void __launch_bounds__(256)
+pad_rows_kernel(float* __restrict__ dst, const float* __restrict__ src, long long rows, int k, int ld) {
+  const long long total = rows * ld;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const long long r = i / ld;
+    const int c = (int)(i - r * ld);
+    dst[i] = c < k ? src[r * k + c] : 0.f;
+  }
+}
+
+hipError_t launch_pad_rows(float* dst, const float* src, long long rows, int k, int ld, hipStream_t s) {
+  if (rows <= 0 || k <= 0) return hipSuccess;
+  long long nb = (rows * ld + 255) / 256;
+  if (nb > 65536) nb = 65536;
+  pad_rows_kernel<<<(int)nb, 256, 0, s>>>(dst, src, rows, k, ld);
+  return hipGetLastError();
 }
 
 hipError_t launch_gather_rows(float* dst, const float* src, const int* idx, int nrows, int k,

@@ -34,27 +34,44 @@ typedef const int __attribute__((address_space(4)))* const_int_ptr;
 
 __device__ __forceinline__ int qsgpr(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
-template <int UU>
+// The value held by the lane that loaded non-zero (step UU, this lane's sub) of the transposed block.
+//   LPE = 16: lane s*16+u holds entry 4u+s   -> DPP row_newbcast:UU (lane UU of every 16-lane row)
+//   LPE =  4: lane s*4+u  holds entry 16u+s  -> DPP quad_perm [UU,UU,UU,UU]
+// (every lane has a source lane, so bound_ctrl is irrelevant)
+template <int LPE, int UU>
 __device__ __forceinline__ int quad_bcast(int v) {
-  return __builtin_amdgcn_mov_dpp(v, 0x150 + UU, 0xf, 0xf, true);              // row_newbcast:UU (every lane has a source)
+  static_assert(LPE == 16 || LPE == 4, "layouts: 16 or 4 lanes per non-zero");
+  if constexpr (LPE == 16) {
+    return __builtin_amdgcn_mov_dpp(v, 0x150 + UU, 0xf, 0xf, true);
+  } else {
+    return __builtin_amdgcn_mov_dpp(v, UU | (UU << 2) | (UU << 4) | (UU << 6), 0xf, 0xf, true);
+  }
 }
 
+// sum over the subs (lane bits >= log2(LPE))
+template <int LPE>
 __device__ __forceinline__ float4 quad_reduce(float4 t) {
-  t.x += __shfl_xor(t.x, 16); t.y += __shfl_xor(t.y, 16);
-  t.z += __shfl_xor(t.z, 16); t.w += __shfl_xor(t.w, 16);
-  t.x += __shfl_xor(t.x, 32); t.y += __shfl_xor(t.y, 32);
-  t.z += __shfl_xor(t.z, 32); t.w += __shfl_xor(t.w, 32);
+#pragma unroll
+  for (int o = LPE; o < 64; o <<= 1) {
+    t.x += __shfl_xor(t.x, o); t.y += __shfl_xor(t.y, o);
+    t.z += __shfl_xor(t.z, o); t.w += __shfl_xor(t.w, o);
+  }
   return t;
 }
 
-template <bool EPI>
+// LPE = lanes per non-zero (each lane a float4): 16 -> 64-column tile, 4 non-zeros per gather
+// instruction; 4 -> 16-column tile (k <= 16), 16 per instruction.  A 64-entry block takes LPE steps of
+// 64/LPE non-zeros.  (An 8-lane / 32-column layout was measured for k = 17..32 and bought nothing over
+// the 16-lane layout with half its lanes idle — 1.61 vs 1.59 ms on the Reddit-shaped graph: narrow
+// widths are bound by L2 requests per non-zero, not by instructions — so it is not instantiated.)
+template <int LPE, bool EPI>
 __global__ void __launch_bounds__(256)
 spmm_quad_kernel(const int* __restrict__ g_rowptr, const int* __restrict__ g_col,
                  const float* __restrict__ g_val, const float* __restrict__ g_B,
                  float* __restrict__ g_C, float* __restrict__ g_P,
                  const int* __restrict__ g_chunk_row, const float* __restrict__ g_bias,
                  const int* __restrict__ nnz_dev,
-                 int relu, int nchunks, int T, int m, int nnz, int k, int col_tile, int accumulate) {
+                 int relu, int nchunks, int T, int m, int nnz, int k, int col_tile, int accumulate, int ldb) {
   if (nnz_dev) {                                    // drop-in (flexspmm) mode, see spmm_kernels.hip
     nnz = *nnz_dev;
     nchunks = (int)(((long long)nnz + T - 1) / T);
@@ -72,12 +89,13 @@ spmm_quad_kernel(const int* __restrict__ g_rowptr, const int* __restrict__ g_col
          (const_int_ptr)(uintptr_t)g_chunk_row, g_bias};
   const int lane = threadIdx.x & 63;
   const int wib  = qsgpr(threadIdx.x >> 6);
-  const int sub  = lane >> 4;
-  const int f    = lane & 15;
-  const int fcol = col_tile * 64 + f * 4;           // first of this lane's four feature columns
+  constexpr int EPS = 64 / LPE;                     // non-zeros per step (= per gather instruction)
+  const int sub  = lane / LPE;
+  const int f    = lane % LPE;
+  const int fcol = col_tile * (4 * LPE) + f * 4;    // first of this lane's four feature columns
   const bool fok = fcol < k;                        // (k % 4 == 0: a float4 is all in or all out)
   const bool writer = fok && sub == 0;
-  const int tl   = f * 4 + sub;                     // transposed position this lane loads
+  const int tl   = f * EPS + sub;                   // transposed position this lane loads
 
   const int xcd           = blockIdx.x & 7;
   const int wave_in_xcd   = (blockIdx.x >> 3) * 4 + wib;
@@ -85,9 +103,10 @@ spmm_quad_kernel(const int* __restrict__ g_rowptr, const int* __restrict__ g_col
   const int c_lo = (int)(((long long)nchunks * xcd) >> 3);
   const int c_hi = (int)(((long long)nchunks * (xcd + 1)) >> 3);
 
-  const unsigned row_bytes = (unsigned)k * 4u;
-  // lanes past k gather columns 0..3 of the same rows (valid memory) and never store
-  const unsigned foff = (unsigned)(fok ? fcol : 0) * 4u;
+  const unsigned row_bytes = (unsigned)ldb * 4u;    // B row stride (>= k: rows may be padded to 128-byte lines)
+  // lanes past k gather the tile's first four columns of the same rows (valid memory, a cache line
+  // the active lanes fetch anyway) and never store
+  const unsigned foff = (unsigned)(fok ? fcol : col_tile * (4 * LPE)) * 4u;
   const char* __restrict__ Bb = reinterpret_cast<const char*>(a.B);
   const size_t kk = (size_t)k;
   float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -107,7 +126,7 @@ spmm_quad_kernel(const int* __restrict__ g_rowptr, const int* __restrict__ g_col
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);   // this lane's (sub, f) partial of the current row
 
     auto flush = [&]() {
-      float4 t = quad_reduce(acc);
+      float4 t = quad_reduce<LPE>(acc);
       if (head) {
         if (writer) *reinterpret_cast<float4*>(a.P + (size_t)(2 * c) * kk + fcol) = t;
       } else {
@@ -140,32 +159,29 @@ spmm_quad_kernel(const int* __restrict__ g_rowptr, const int* __restrict__ g_col
       cj_nx = 0; vj_nx = 0.f;
       if (base + 64 + tl < end) { cj_nx = a.col[base + 64 + tl]; vj_nx = a.val[base + 64 + tl]; }
 
-      float4 b[16];
+      float4 b[LPE];
 #define GCN_Q_GATHER(UU)                                                                         \
-      b[UU] = *reinterpret_cast<const float4*>(                                                  \
-          Bb + (size_t)(__umul24((unsigned)quad_bcast<UU>(cj), row_bytes) + foff));
-#define GCN_Q_VAL(UU) __builtin_bit_cast(float, quad_bcast<UU>(vj))
+      if constexpr (UU < LPE)                                                                    \
+        b[UU] = *reinterpret_cast<const float4*>(                                                \
+            Bb + (size_t)(__umul24((unsigned)quad_bcast<LPE, UU>(cj), row_bytes) + foff));
+#define GCN_Q_VAL(UU) __builtin_bit_cast(float, quad_bcast<LPE, UU>(vj))
+#define GCN_Q_ALL(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15)
       // entries past `cnt` carry col = 0, val = 0: they gather row 0 (valid memory) and are
       // masked out below, never multiplied in
-      GCN_Q_GATHER(0) GCN_Q_GATHER(1) GCN_Q_GATHER(2) GCN_Q_GATHER(3)
-      GCN_Q_GATHER(4) GCN_Q_GATHER(5) GCN_Q_GATHER(6) GCN_Q_GATHER(7)
-      GCN_Q_GATHER(8) GCN_Q_GATHER(9) GCN_Q_GATHER(10) GCN_Q_GATHER(11)
-      GCN_Q_GATHER(12) GCN_Q_GATHER(13) GCN_Q_GATHER(14) GCN_Q_GATHER(15)
+      GCN_Q_ALL(GCN_Q_GATHER)
       if (cnt == 64 && (row_end < 0 || row_end - pos >= 64)) {
         // fast path: all 64 non-zeros belong to the current row
 #define GCN_Q_FMA(UU)                                                                            \
-        { const float v = GCN_Q_VAL(UU);                                                         \
+        if constexpr (UU < LPE) {                                                                \
+          const float v = GCN_Q_VAL(UU);                                                         \
           acc.x = fmaf(v, b[UU].x, acc.x); acc.y = fmaf(v, b[UU].y, acc.y);                      \
           acc.z = fmaf(v, b[UU].z, acc.z); acc.w = fmaf(v, b[UU].w, acc.w); }
-        GCN_Q_FMA(0) GCN_Q_FMA(1) GCN_Q_FMA(2) GCN_Q_FMA(3)
-        GCN_Q_FMA(4) GCN_Q_FMA(5) GCN_Q_FMA(6) GCN_Q_FMA(7)
-        GCN_Q_FMA(8) GCN_Q_FMA(9) GCN_Q_FMA(10) GCN_Q_FMA(11)
-        GCN_Q_FMA(12) GCN_Q_FMA(13) GCN_Q_FMA(14) GCN_Q_FMA(15)
+        GCN_Q_ALL(GCN_Q_FMA)
 #undef GCN_Q_FMA
         pos += 64;
         while (pos == row_end) flush();
       } else {
-        // rows end inside this block (or it is the ragged last block): one pass over the 16 steps
+        // rows end inside this block (or it is the ragged last block): one pass over the steps
         // per row segment [q0, q1) of the block, each lane adding only the products of its own
         // non-zeros that lie in the segment (masked on the product, so a NaN/Inf in a feature row
         // never leaks into a row of A that does not reference it)
@@ -174,14 +190,12 @@ spmm_quad_kernel(const int* __restrict__ g_rowptr, const int* __restrict__ g_col
           const int q1 = row_end < 0 ? cnt : min(cnt, row_end - base);
           const unsigned lo = (unsigned)(q0 - sub), len = (unsigned)(q1 - q0);
 #define GCN_Q_SEG(UU)                                                                            \
-          { const bool in = (unsigned)(UU * 4) - lo < len;                                       \
+          if constexpr (UU < LPE) {                                                              \
+            const bool in = (unsigned)(UU * EPS) - lo < len;      /* entry UU*EPS + sub in [q0, q1) */ \
             const float v = GCN_Q_VAL(UU);                                                       \
             acc.x = in ? fmaf(v, b[UU].x, acc.x) : acc.x; acc.y = in ? fmaf(v, b[UU].y, acc.y) : acc.y; \
             acc.z = in ? fmaf(v, b[UU].z, acc.z) : acc.z; acc.w = in ? fmaf(v, b[UU].w, acc.w) : acc.w; }
-          GCN_Q_SEG(0) GCN_Q_SEG(1) GCN_Q_SEG(2) GCN_Q_SEG(3)
-          GCN_Q_SEG(4) GCN_Q_SEG(5) GCN_Q_SEG(6) GCN_Q_SEG(7)
-          GCN_Q_SEG(8) GCN_Q_SEG(9) GCN_Q_SEG(10) GCN_Q_SEG(11)
-          GCN_Q_SEG(12) GCN_Q_SEG(13) GCN_Q_SEG(14) GCN_Q_SEG(15)
+          GCN_Q_ALL(GCN_Q_SEG)
 #undef GCN_Q_SEG
           pos = base + q1;
           if (pos != row_end) break;                // the row goes on past this block
@@ -190,12 +204,13 @@ spmm_quad_kernel(const int* __restrict__ g_rowptr, const int* __restrict__ g_col
           if (q0 >= cnt) break;
         }
       }
+#undef GCN_Q_ALL
 #undef GCN_Q_GATHER
 #undef GCN_Q_VAL
     }
 
     if (last_flush != end) {                        // the row piece that sticks out of the chunk
-      const float4 t = quad_reduce(acc);
+      const float4 t = quad_reduce<LPE>(acc);
       const int slot = head ? 2 * c : 2 * c + 1;
       if (writer) *reinterpret_cast<float4*>(a.P + (size_t)slot * kk + fcol) = t;
     }
@@ -204,20 +219,32 @@ spmm_quad_kernel(const int* __restrict__ g_rowptr, const int* __restrict__ g_col
 
 bool spmm_quad_eligible(const SpmmArgs& a) {
   const uintptr_t al = (uintptr_t)a.B | (uintptr_t)a.C | (uintptr_t)a.P | (uintptr_t)a.bias;
-  return a.k % 4 == 0 && (al & 15) == 0 && a.n < (1 << 24) && a.k * 4 < (1 << 24) &&
-         (unsigned long long)a.n * (unsigned long long)a.k * 4ull < 0xFFFFFFF0ull;
+  const int ldb = a.ldb > 0 ? a.ldb : a.k;
+  return a.k % 4 == 0 && ldb % 4 == 0 && (al & 15) == 0 && a.n < (1 << 24) && ldb * 4 < (1 << 24) &&
+         (unsigned long long)a.n * (unsigned long long)ldb * 4ull < 0xFFFFFFF0ull;
 }
 
-hipError_t launch_spmm_quad(const SpmmArgs& a, int nblocks, bool epi, hipStream_t s) {
-  const int tiles = (a.k + 63) / 64;
+template <int LPE>
+static hipError_t launch_quad(const SpmmArgs& a, int nblocks, bool epi, hipStream_t s) {
+  const int tiles = (a.k + 4 * LPE - 1) / (4 * LPE);
   for (int t = 0; t < tiles; ++t) {
 #define GCN_QUAD_ARGS a.rowptr, a.col, a.val, a.B, a.C, a.P, a.chunk_row, a.bias, a.nnz_dev, \
-                      a.relu, a.nchunks, a.T, a.m, a.nnz, a.k, t, a.accumulate
-    if (epi) spmm_quad_kernel<true><<<dim3(nblocks), dim3(256), 0, s>>>(GCN_QUAD_ARGS);
-    else     spmm_quad_kernel<false><<<dim3(nblocks), dim3(256), 0, s>>>(GCN_QUAD_ARGS);
+                      a.relu, a.nchunks, a.T, a.m, a.nnz, a.k, t, a.accumulate, (a.ldb > 0 ? a.ldb : a.k)
+    if (epi) spmm_quad_kernel<LPE, true><<<dim3(nblocks), dim3(256), 0, s>>>(GCN_QUAD_ARGS);
+    else     spmm_quad_kernel<LPE, false><<<dim3(nblocks), dim3(256), 0, s>>>(GCN_QUAD_ARGS);
 #undef GCN_QUAD_ARGS
   }
   return hipGetLastError();
+}
+
+// lanes per non-zero for a k-wide SpMM: the narrowest layout whose tile (4*LPE columns) covers k
+int spmm_quad_lanes(int k) { return k <= 16 ? 4 : 16; }
+
+hipError_t launch_spmm_quad(const SpmmArgs& a, int nblocks, bool epi, hipStream_t s) {
+  switch (spmm_quad_lanes(a.k)) {
+    case 4:  return launch_quad<4>(a, nblocks, epi, s);
+    default: return launch_quad<16>(a, nblocks, epi, s);
+  }
 }
 
 }  // namespace gcn

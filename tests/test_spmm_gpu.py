@@ -102,7 +102,7 @@ def test_edge_cases_empty_and_tiny():
     assert rel_err(C, Cref) <= TOL
 
 
-@pytest.mark.parametrize("k", [4, 8, 16, 33, 64, 128, 256])
+@pytest.mark.parametrize("k", [4, 8, 16, 20, 33, 47, 64, 100, 128, 256])       # 20, 47, 100: padded feature rows
 def test_nan_inf_do_not_leak_between_rows(k):
     """a row of B holding Inf/NaN only poisons the output rows that reference it — for every kernel
     family (narrow k <= 16, one-non-zero-per-gather, four-per-gather).  Row 0 is the row the kernels'
@@ -123,7 +123,7 @@ def test_nan_inf_do_not_leak_between_rows(k):
 
 
 @pytest.mark.parametrize("width", [1, 4])
-@pytest.mark.parametrize("k", [20, 64, 128, 200])
+@pytest.mark.parametrize("k", [12, 16, 20, 32, 64, 128, 200])
 def test_parity_gather_widths(width, k):
     """the 64-column tile with one and with four non-zeros per gather instruction
     (gcn_spmm_plan_set_gather_width), on ragged input: empty rows, hub rows, rows of 1..5 non-zeros,
@@ -155,11 +155,16 @@ def test_main_kernel_families_are_selected_as_documented():
     rowptr, col, val = random_csr(m, n, 20000, seed=1)
     adj = _adj(rowptr, col, val, m, n)
     assert adj.main_kernel(4).startswith("gcn::spmm_narrow_kernel<4,")
-    assert adj.main_kernel(16) == "gcn::spmm_narrow16_dpp_kernel<false>"
+    assert adj.main_kernel(8).startswith("gcn::spmm_narrow_kernel<8,")
+    assert adj.main_kernel(15) == "gcn::spmm_narrow16_dpp_kernel<false>"
+    assert adj.main_kernel(16) == "gcn::spmm_quad_kernel<4, false>"          # 16 non-zeros per gather
     assert adj.main_kernel(17).startswith("gcn::spmm_chunk_kernel<1,")
-    assert adj.main_kernel(32) == "gcn::spmm_quad_kernel<false>"
-    assert adj.main_kernel(128) == "gcn::spmm_quad_kernel<false>"
-    assert adj.main_kernel(128, epilogue=True) == "gcn::spmm_quad_kernel<true>"
+    assert adj.main_kernel(32) == "gcn::spmm_quad_kernel<16, false>"         # 4 per gather, half the lanes idle
+    assert adj.main_kernel(128) == "gcn::spmm_quad_kernel<16, false>"        # 4 per gather
+    assert adj.main_kernel(128, epilogue=True) == "gcn::spmm_quad_kernel<16, true>"
+    adj.set_gather_width(1)
+    assert adj.main_kernel(16) == "gcn::spmm_narrow16_dpp_kernel<false>"
+    adj.set_gather_width(0)
     assert adj.main_kernel(130).startswith("gcn::spmm_chunk_kernel<1,")      # k % 4 != 0
     adj.set_tile_cols(256)
     assert adj.main_kernel(256).startswith("gcn::spmm_chunk_kernel<4,")
