@@ -871,7 +871,21 @@ void flexspmm(int* seg_rowPtr, float* segNzCV, int* segVoMap, int* grouped_tailS
   a.nnz_dev = seg_rowPtr + vm;           // exact nnz lives at the end of the (virtual) row pointer
   a.nchunks_grid = nchunks_ub;
   a.tile_cols = S > 0 ? 64 : auto_tile_cols(n, k);
-  hipError_t e = gcn::launch_spmm(a, cu, (hipStream_t) nullptr);         // legacy default stream
+  hipError_t e;
+  if (const int ldb = padded_ldb(n, k); ldb != k) {                      // odd widths: rows on whole lines
+    const size_t need = sizeof(float) * (size_t)n * (size_t)ldb;
+    if (need > scratch.bpad_bytes) {
+      if (scratch.bpad) (void)hipFree(scratch.bpad);
+      scratch.bpad = nullptr; scratch.bpad_bytes = 0;
+      if (hipMalloc((void**)&scratch.bpad, need) != hipSuccess) die("flexspmm padded features", hipErrorOutOfMemory);
+      scratch.bpad_bytes = need;
+    }
+    e = gcn::launch_pad_rows(scratch.bpad, B, n, k, ldb, (hipStream_t) nullptr);
+    if (e != hipSuccess) die("flexspmm feature padding", e);
+    a.B = scratch.bpad;
+    a.ldb = ldb;
+  }
+  e = gcn::launch_spmm(a, cu, (hipStream_t) nullptr);                    // legacy default stream
   if (e != hipSuccess) die("flexspmm launch", e);
   if (S > 0) {
     e = gcn::launch_slice_reduce(scratch.cv, C, nullptr, 0, m, S, k, (hipStream_t) nullptr);
