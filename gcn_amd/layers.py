@@ -171,10 +171,11 @@ class GCN(nn.Module):
         return self
 
     def fit(self, features, adj, labels, idx_train, train_iters=200, initialize=True, verbose=False,
-            normalize=True):
+            normalize=True, reuse_prepared=False):
         if initialize:
             self.initialize()
-        self.prepare(features, adj, labels, normalize)
+        if not (reuse_prepared and self.adj is not None):   # (a second fit on the same graph keeps steps 1-4)
+            self.prepare(features, adj, labels, normalize)
         idx = self._new_index[torch.as_tensor(np.asarray(idx_train)).long()].to(self.labels.device)
         self.train()
         opt = torch.optim.Adam(self.parameters(), lr=self.lr, weight_decay=self.weight_decay)
