@@ -40,6 +40,8 @@ struct gcn_spmm_plan {
   size_t cv_bytes;
   float* bpad;                  // B re-laid with rows padded to whole 128-byte lines (odd k), grow-only
   size_t bpad_bytes;
+  float* cpad;                  // result with k rounded up to a multiple of 4 (k % 4 != 0), grow-only
+  size_t cpad_bytes;
   // LDS-staged row panels (spmm_panel.hip): rows per panel, 0 = off; measured window coverage
   int panel_R;
   int* panel_w0;                // device [ceil(m / panel_R)]: first column of each panel's window
@@ -221,6 +223,7 @@ int gcn_spmm_plan_create(gcn_spmm_plan_t** out, const int32_t* rowptr_dev, int32
   p->prof_cap = p->prof_n = 0;
   p->tile_cols = 0;
   p->bpad = nullptr; p->bpad_bytes = 0;
+  p->cpad = nullptr; p->cpad_bytes = 0;
   p->blocks_per_cu = 32;
   p->gather_width = 0;
   (void)hipGetDevice(&p->device);
@@ -247,6 +250,7 @@ int gcn_spmm_plan_destroy(gcn_spmm_plan_t* p) {
   if (p->vchunk_row) (void)hipFree(p->vchunk_row);
   if (p->cv) (void)hipFree(p->cv);
   if (p->bpad) (void)hipFree(p->bpad);
+  if (p->cpad) (void)hipFree(p->cpad);
   {
     void* ptrs[] = {p->panel_w0, p->pin_rowptr, p->pin_off, p->pin_val, p->pout_rowptr, p->pout_col,
                     p->pout_val, p->pout_chunk_row};
@@ -265,12 +269,51 @@ size_t gcn_spmm_plan_workspace_bytes(const gcn_spmm_plan_t* p, int32_t k) {
   return sizeof(float) * 2 * (size_t)(chunks > 0 ? chunks : 1) * (size_t)k;
 }
 
+static int grow(float*& buf, size_t& have, size_t need) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (need <= have) return GCN_OK;
+  if (buf) (void)hipFree(buf);
+  buf = nullptr; have = 0;
+  if (hipMalloc((void**)&buf, need) != hipSuccess) return GCN_ERR_ALLOC;
+  have = need;
+  return GCN_OK;
+}
+
+// b_ld: row stride of B in floats when the caller of this function has already re-laid it, 0 = k
+static int spmm_impl(gcn_spmm_plan_t* p, const int32_t* rowptr, const int32_t* col, const float* val,
+                     const float* B, int b_ld, float* C, const float* bias, int32_t relu, int32_t k,
+                     void* stream);
+
 int gcn_spmm_csr_f32_bias_relu(gcn_spmm_plan_t* p, const int32_t* rowptr, const int32_t* col,
                                const float* val, const float* B, float* C, const float* bias,
                                int32_t relu, int32_t k, void* stream) {
   if (!p || k < 0) return GCN_ERR_INVALID_ARG;
   if (p->m == 0 || k == 0) return GCN_OK;
   if (!C || !rowptr || (p->nnz > 0 && (!col || !val || !B))) return GCN_ERR_INVALID_ARG;
+  // Widths that are not a multiple of 4 (class counts: 41, 47, ...) cannot use the 16-byte-per-lane
+  // kernel on the caller's layout.  They are computed at k' = k rounded up to 4 on row-padded copies:
+  // B re-laid with zero columns (stride a multiple of 32 floats), the product into a k'-wide scratch
+  // result, and one pass that compacts it into C (and applies the epilogue).  Reddit-shaped k = 41:
+  // 2.13 -> 1.87 ms.  Same limits as the B padding above (tables <= 768 MiB), panels excluded.
+  if (k > 16 && k % 4 != 0 && p->nnz > 0 && p->panel_R == 0 && p->gather_width != 1 && pad_b_enabled()) {
+    const int kp = (k + 3) / 4 * 4, ldb = (kp + 31) / 32 * 32;
+    if ((long long)sizeof(float) * p->n * ldb <= (768LL << 20)) {
+      int st = grow(p->bpad, p->bpad_bytes, sizeof(float) * (size_t)p->n * (size_t)ldb);
+      if (st == GCN_OK) st = grow(p->cpad, p->cpad_bytes, sizeof(float) * (size_t)p->m * (size_t)kp);
+      if (st != GCN_OK) return st;
+      if (gcn::launch_pad_rows(p->bpad, B, p->n, k, ldb, (hipStream_t)stream) != hipSuccess) return GCN_ERR_HIP;
+      st = spmm_impl(p, rowptr, col, val, p->bpad, ldb, p->cpad, nullptr, 0, kp, stream);
+      if (st != GCN_OK) return st;
+      return gcn::launch_unpad_rows(C, p->cpad, bias, relu ? 1 : 0, p->m, k, kp, (hipStream_t)stream) == hipSuccess
+                 ? GCN_OK : GCN_ERR_HIP;
+    }
+  }
+  return spmm_impl(p, rowptr, col, val, B, 0, C, bias, relu, k, stream);
+}
+
+static int spmm_impl(gcn_spmm_plan_t* p, const int32_t* rowptr, const int32_t* col, const float* val,
+                     const float* B, int b_ld, float* C, const float* bias, int32_t relu, int32_t k,
+                     void* stream) {
   {
     std::lock_guard<std::mutex> lk(g_mu);
     const int st = ensure_ws(p, k);
@@ -285,17 +328,11 @@ int gcn_spmm_csr_f32_bias_relu(gcn_spmm_plan_t* p, const int32_t* rowptr, const 
   // then costs up to one extra L2 request per tile.  Where that matters (padded_ldb) B is first re-laid
   // with its rows padded to the next multiple of 32 floats (one streaming copy, ~45 us for 233 k x 100)
   // and gathered from there; C keeps the caller's layout.
-  if (const int ldb = padded_ldb(p->n, k); p->nnz > 0 && ldb != k) {
-    const size_t need = sizeof(float) * (size_t)p->n * (size_t)ldb;
-    {
-      std::lock_guard<std::mutex> lk(g_mu);
-      if (need > p->bpad_bytes) {
-        if (p->bpad) (void)hipFree(p->bpad);
-        p->bpad = nullptr; p->bpad_bytes = 0;
-        if (hipMalloc((void**)&p->bpad, need) != hipSuccess) return GCN_ERR_ALLOC;
-        p->bpad_bytes = need;
-      }
-    }
+  if (b_ld > 0) {
+    a.ldb = b_ld;                                      // already re-laid by the caller (odd-width path)
+  } else if (const int ldb = padded_ldb(p->n, k); p->nnz > 0 && ldb != k) {
+    const int st = grow(p->bpad, p->bpad_bytes, sizeof(float) * (size_t)p->n * (size_t)ldb);
+    if (st != GCN_OK) return st;
     if (gcn::launch_pad_rows(p->bpad, B, p->n, k, ldb, (hipStream_t)stream) != hipSuccess) return GCN_ERR_HIP;
     a.B = p->bpad;
     a.ldb = ldb;
@@ -510,7 +547,12 @@ int gcn_spmm_plan_main_kernel(const gcn_spmm_plan_t* p, int32_t k, int32_t epilo
   a.relu = epilogue && !sliced ? 1 : 0;               // sliced: the epilogue runs in the slice reduction
   a.tile_cols = p->tile_cols ? p->tile_cols : (sliced ? 64 : auto_tile_cols(p->n, k));
   a.gather_width = p->gather_width;
-  if (const int ldb = padded_ldb(p->n, k); ldb != k) a.ldb = ldb;
+  if (k > 16 && k % 4 != 0 && p->panel_R == 0 && p->gather_width != 1 && pad_b_enabled() &&
+      (long long)sizeof(float) * p->n * (((k + 3) / 4 * 4 + 31) / 32 * 32) <= (768LL << 20)) {
+    a.k = (k + 3) / 4 * 4;                             // odd widths run at k rounded up to 4 (see gcn_spmm_csr_f32_bias_relu)
+    a.ldb = (a.k + 31) / 32 * 32;
+    a.relu = 0;
+  } else if (const int ldb = padded_ldb(p->n, k); ldb != k) a.ldb = ldb;
   gcn::describe_main_kernel(a, buf, (size_t)buflen);
   return GCN_OK;
 }

@@ -44,6 +44,9 @@ hipError_t launch_gather_rows(float* dst, const float* src, const int* idx, int 
                               hipStream_t s);
 // dst[r, 0:k] = src[r, 0:k], dst[r, k:ld] = 0 for r < rows (dst row stride ld >= k)
 hipError_t launch_pad_rows(float* dst, const float* src, long long rows, int k, int ld, hipStream_t s);
+// dst[r, 0:k] = act(src[r, 0:k] + bias), src row stride ld >= k
+hipError_t launch_unpad_rows(float* dst, const float* src, const float* bias, int relu, long long rows, int k,
+                             int ld, hipStream_t s);
 int pick_vec(int k, int tile_cols, const void* B, const void* C, const void* P);
 void describe_main_kernel(const SpmmArgs& a, char* buf, size_t len);
 

@@ -497,6 +497,31 @@ hipError_t launch_pad_rows(float* dst, const float* src, long long rows, int k, 
   return hipGetLastError();
 }
 
+// dst[r, 0:k] = act(src[r, 0:k] + bias): the compact result out of a row-padded one (src row stride ld)
+__global__ void __launch_bounds__(256)
+unpad_rows_kernel(float* __restrict__ dst, const float* __restrict__ src, const float* __restrict__ bias,
+                  int relu, long long rows, int k, int ld) {
+  const long long total = rows * k;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const long long r = i / k;
+    const int c = (int)(i - r * k);
+    float v = src[r * ld + c];
+    if (bias) v += bias[c];
+    if (relu) v = fmaxf(v, 0.f);
+    dst[i] = v;
+  }
+}
+
+hipError_t launch_unpad_rows(float* dst, const float* src, const float* bias, int relu, long long rows, int k,
+                             int ld, hipStream_t s) {
+  if (rows <= 0 || k <= 0) return hipSuccess;
+  long long nb = (rows * k + 255) / 256;
+  if (nb > 65536) nb = 65536;
+  unpad_rows_kernel<<<(int)nb, 256, 0, s>>>(dst, src, bias, relu, rows, k, ld);
+  return hipGetLastError();
+}
+
 hipError_t launch_gather_rows(float* dst, const float* src, const int* idx, int nrows, int k,
                               hipStream_t s) {
   if (nrows <= 0 || k <= 0) return hipSuccess;

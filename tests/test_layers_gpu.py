@@ -67,3 +67,21 @@ def test_training_reduces_the_loss_and_timers_report():
     rep = model.timing_report()
     assert "layer1 xw" in rep and "layer2 xw" in rep and model.gc1.timers.c.af.n_calls >= 60
     assert model.gc1.timers.c.af.avms() > 0          # HIP-event timer on the SpMM interval
+
+
+def test_layer_order_auto_runs_the_spmm_at_the_narrower_width_with_the_same_result():
+    """(ÂX)W and Â(XW) are the same function; 'auto' picks the one whose SpMM is narrower (§8f.1)"""
+    g, n, raw, X = _golden_problem()
+    nfeat, nhid, ncls = int(g["nfeat"]), int(g["nhid"]), int(g["ncls"])
+    outs = {}
+    for lo in ("reference", "auto"):
+        model = gcn_amd.GCN(nfeat, nhid, ncls, dataset="reddit", device="cuda:0", order=None, layer_order=lo).to("cuda:0")
+        _load_weights(model, g)
+        model.prepare(X, raw, np.zeros(n, dtype=np.int64))
+        outs[lo] = (type(model.gc2).__name__, model.predict().cpu().numpy())
+    assert outs["reference"][0] == "GraphConvolution2"                     # gcn6.py:214-218 for 'reddit'
+    assert outs["auto"][0] == ("GraphConvolution" if ncls <= nhid else "GraphConvolution2")
+    assert rel_err(outs["auto"][1], outs["reference"][1]) <= 1e-5
+    assert rel_err(outs["auto"][1], g["out"]) <= 1e-5
+    with pytest.raises(ValueError):
+        gcn_amd.GCN(nfeat, nhid, ncls, device="cuda:0", layer_order="fastest")

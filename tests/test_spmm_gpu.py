@@ -158,14 +158,18 @@ def test_main_kernel_families_are_selected_as_documented():
     assert adj.main_kernel(8).startswith("gcn::spmm_narrow_kernel<8,")
     assert adj.main_kernel(15) == "gcn::spmm_narrow16_dpp_kernel<false>"
     assert adj.main_kernel(16) == "gcn::spmm_quad_kernel<4, false>"          # 16 non-zeros per gather
-    assert adj.main_kernel(17).startswith("gcn::spmm_chunk_kernel<1,")
+    assert adj.main_kernel(17) == "gcn::spmm_quad_kernel<16, false>"         # odd widths run at k rounded up to 4
     assert adj.main_kernel(32) == "gcn::spmm_quad_kernel<16, false>"         # 4 per gather, half the lanes idle
     assert adj.main_kernel(128) == "gcn::spmm_quad_kernel<16, false>"        # 4 per gather
     assert adj.main_kernel(128, epilogue=True) == "gcn::spmm_quad_kernel<16, true>"
     adj.set_gather_width(1)
     assert adj.main_kernel(16) == "gcn::spmm_narrow16_dpp_kernel<false>"
     adj.set_gather_width(0)
-    assert adj.main_kernel(130).startswith("gcn::spmm_chunk_kernel<1,")      # k % 4 != 0
+    assert adj.main_kernel(130) == "gcn::spmm_quad_kernel<16, false>"        # k' = 132
+    adj.set_gather_width(1)
+    assert adj.main_kernel(130).startswith("gcn::spmm_chunk_kernel<1,")      # one non-zero per gather, caller's layout
+    assert adj.main_kernel(128).startswith("gcn::spmm_chunk_kernel<1,")
+    adj.set_gather_width(0)
     adj.set_tile_cols(256)
     assert adj.main_kernel(256).startswith("gcn::spmm_chunk_kernel<4,")
     adj.set_tile_cols(128)
