@@ -890,38 +890,38 @@ void flexspmm(int* seg_rowPtr, float* segNzCV, int* segVoMap, int* grouped_tailS
   const int vm = S > 0 ? S * m : m;
   const long long nnz_ub = 9LL * n_segs + 8;
   const int nchunks_ub = (int)((nnz_ub + T - 1) / T);
+  // odd widths: computed at k' = k rounded up to 4 on row-padded copies, as in gcn_spmm_csr_f32_bias_relu
+  const bool odd = k > 16 && k % 4 != 0 && pad_b_enabled() &&
+                   (long long)sizeof(float) * n * (((k + 3) / 4 * 4 + 31) / 32 * 32) <= (768LL << 20);
+  const int kc = odd ? (k + 3) / 4 * 4 : k;                      // width the kernels compute at
+  const int ldb = odd ? (kc + 31) / 32 * 32 : padded_ldb(n, k);  // row stride B is gathered with
   std::lock_guard<std::mutex> lk(g_mu);
   scratch.nchunks = nchunks_ub;
-  if (ensure_ws(&scratch, k) != GCN_OK) die("flexspmm workspace", hipErrorOutOfMemory);
-  if (S > 0) {
-    const size_t need = sizeof(float) * (size_t)vm * (size_t)k;
-    if (need > scratch.cv_bytes) {
-      if (scratch.cv) (void)hipFree(scratch.cv);
-      scratch.cv = nullptr; scratch.cv_bytes = 0;
-      if (hipMalloc((void**)&scratch.cv, need) != hipSuccess) die("flexspmm slice buffer", hipErrorOutOfMemory);
-      scratch.cv_bytes = need;
-    }
-  }
+  if (ensure_ws(&scratch, kc) != GCN_OK) die("flexspmm workspace", hipErrorOutOfMemory);
+  auto grow_or_die = [](float*& buf, size_t& have, size_t need, const char* what) {
+    if (need <= have) return;
+    if (buf) (void)hipFree(buf);
+    buf = nullptr; have = 0;
+    if (hipMalloc((void**)&buf, need) != hipSuccess) die(what, hipErrorOutOfMemory);
+    have = need;
+  };
+  if (S > 0) grow_or_die(scratch.cv, scratch.cv_bytes, sizeof(float) * (size_t)vm * (size_t)kc, "flexspmm slice buffer");
+  if (odd) grow_or_die(scratch.cpad, scratch.cpad_bytes, sizeof(float) * (size_t)m * (size_t)kc, "flexspmm padded result");
   gcn::SpmmArgs a;
   a.rowptr = seg_rowPtr;
   a.col = reinterpret_cast<const int*>(segNzCV);
   a.val = nullptr;                       // = segNzCV + nnz, resolved on the device
-  a.B = B; a.C = S > 0 ? scratch.cv : C; a.P = scratch.ws; a.chunk_row = segVoMap;   // (the packed
+  float* Cc = odd ? scratch.cpad : C;    // compact-width or padded-width result
+  a.B = B; a.C = S > 0 ? scratch.cv : Cc; a.P = scratch.ws; a.chunk_row = segVoMap;   // (the packed
   // layout is fixed by csr2tile, so the drop-in pair slices for every k once the graph qualifies)
   a.bias = nullptr; a.relu = 0;
-  a.nchunks = 0; a.T = T; a.m = vm; a.nnz = 0; a.k = k; a.n = n;
+  a.nchunks = 0; a.T = T; a.m = vm; a.nnz = 0; a.k = kc; a.n = n;
   a.nnz_dev = seg_rowPtr + vm;           // exact nnz lives at the end of the (virtual) row pointer
   a.nchunks_grid = nchunks_ub;
-  a.tile_cols = S > 0 ? 64 : auto_tile_cols(n, k);
+  a.tile_cols = S > 0 ? 64 : auto_tile_cols(n, kc);
   hipError_t e;
-  if (const int ldb = padded_ldb(n, k); ldb != k) {                      // odd widths: rows on whole lines
-    const size_t need = sizeof(float) * (size_t)n * (size_t)ldb;
-    if (need > scratch.bpad_bytes) {
-      if (scratch.bpad) (void)hipFree(scratch.bpad);
-      scratch.bpad = nullptr; scratch.bpad_bytes = 0;
-      if (hipMalloc((void**)&scratch.bpad, need) != hipSuccess) die("flexspmm padded features", hipErrorOutOfMemory);
-      scratch.bpad_bytes = need;
-    }
+  if (ldb != k) {                        // rows on whole cache lines (and zero columns up to k')
+    grow_or_die(scratch.bpad, scratch.bpad_bytes, sizeof(float) * (size_t)n * (size_t)ldb, "flexspmm padded features");
     e = gcn::launch_pad_rows(scratch.bpad, B, n, k, ldb, (hipStream_t) nullptr);
     if (e != hipSuccess) die("flexspmm feature padding", e);
     a.B = scratch.bpad;
@@ -930,8 +930,12 @@ void flexspmm(int* seg_rowPtr, float* segNzCV, int* segVoMap, int* grouped_tailS
   e = gcn::launch_spmm(a, cu, (hipStream_t) nullptr);                    // legacy default stream
   if (e != hipSuccess) die("flexspmm launch", e);
   if (S > 0) {
-    e = gcn::launch_slice_reduce(scratch.cv, C, nullptr, 0, m, S, k, (hipStream_t) nullptr);
+    e = gcn::launch_slice_reduce(scratch.cv, Cc, nullptr, 0, m, S, kc, (hipStream_t) nullptr);
     if (e != hipSuccess) die("flexspmm slice reduction", e);
+  }
+  if (odd) {
+    e = gcn::launch_unpad_rows(C, scratch.cpad, nullptr, 0, m, k, kc, (hipStream_t) nullptr);
+    if (e != hipSuccess) die("flexspmm result compaction", e);
   }
 }
 

@@ -268,7 +268,7 @@ def test_dropin_csr2tile_flexspmm_permutate_cuspmm():
     assert tail.numel() == 256 and nxt.numel() == 256               # defect D2: never 257 entries
     dev = [t.to(d) for t in (seg_rowPtr, segNzCV, segVoMap, tail, nxt)]
     rng = np.random.default_rng(3)
-    for k in (16, 47, 100, 128):
+    for k in (16, 41, 47, 100, 128):
         X = rng.standard_normal((n, k)).astype(np.float32)
         Xd = torch.from_numpy(X).to(d).requires_grad_(True)
         out = dropin.flexspmm.apply(dev[0], dev[1], dev[2], n, n, int(n_segs[0]), dev[3], dev[4], Xd)
@@ -434,7 +434,7 @@ def test_dropin_pair_with_xcd_slicing_on_a_dense_graph():
     assert int(seg_rowPtr[S * n]) == nnz and int(seg_rowPtr[n]) < nnz
     dev = [t.to(d) for t in (seg_rowPtr, segNzCV, segVoMap, tail, nxt)]
     rng = np.random.default_rng(5)
-    for k in (16, 128, 200):
+    for k in (16, 41, 128, 200):
         X = rng.standard_normal((n, k)).astype(np.float32)
         Xd = torch.from_numpy(X).to(d)
         C = dropin.flexspmm.apply(dev[0], dev[1], dev[2], n, n, int(n_segs[0]), dev[3], dev[4], Xd)
