@@ -95,6 +95,8 @@ def main():
     ap.add_argument("--gather-width", type=int, default=-1,
                     help="debug: non-zeros per gather instruction of the 64-column kernel (0 auto, 1, 4)")
     ap.add_argument("--blocks-per-cu", type=int, default=0, help="debug: persistent-grid blocks per CU (1..8)")
+    ap.add_argument("--no-plane-streams", action="store_true",
+                    help="debug: N > 1 / --sim-world: all column planes on one stream (default: one stream per plane)")
     ap.add_argument("--sim-world", type=int, default=0,
                     help="debug: on ONE GPU, time rank 0's row block of a W-way partition (compute only, "
                          "no collective) — a rehearsal of the per-rank work at N = W, not a metric")
@@ -158,16 +160,17 @@ def main():
         if sim:
             shard.collective = False
         # column planes of 64: the RCCL all-gather of one plane overlaps the SpMM of the next
-        pipe = PipelinedAggregation(shard, k, dev, plane_cols=64)
+        pipe = PipelinedAggregation(shard, k, dev, plane_cols=64, streams=False if args.no_plane_streams else None)
         pipe.load(H)
         if world > 1 or sim:
-            # 3 blocks (12 waves) per CU: the four-per-gather kernel holds 108 VGPRs, so 4 blocks per CU
-            # is all that fits; a persistent grid of 3 leaves a wave slot and ~170 VGPRs per SIMD free so
-            # that the RCCL all-gather kernel runs BESIDE the next plane's SpMM instead of queueing
-            # behind it.  Rank-0 share of an 8-way partition, compute only (profiles/r01f_sim8_quad.log):
-            # 0.553 ms at 3 blocks/CU vs 0.527 ms at 8 (= 2 rounds of 4) vs 0.572 ms for the
-            # one-per-gather kernel at 6 blocks/CU.
-            shard.local.set_blocks_per_cu(3)
+            # One stream + one operator per plane (PipelinedAggregation): the tail kernels and launch gaps of
+            # one plane hide under the main kernel of the other.  Grid of 8 blocks per CU and plane: the two
+            # concurrent main kernels keep every CU full (4 resident blocks of the 108-VGPR kernel) and are
+            # 4x oversubscribed together, so blocks retire every few tens of microseconds and the RCCL
+            # all-gather (high-priority stream) gets its workgroups in as they do.  Rank-0 share of an 8-way
+            # partition, compute only (profiles/r01f_sim8_streams.log): 0.501 ms/step, against 0.546 ms on one
+            # stream with 3 blocks per CU held free for RCCL, 0.527 ms on one stream with 8.
+            pipe.set_local_option("set_blocks_per_cu", 8)
         launches_per_step = len(pipe.widths)
 
         def step():                       # layer l+1 consumes the all-gathered output of layer l
@@ -189,10 +192,10 @@ def main():
         del rowptr, col, val
         torch.cuda.empty_cache()
 
-    if args.gather_width >= 0:
-        local_adj.set_gather_width(args.gather_width)
-    if args.blocks_per_cu > 0:
-        local_adj.set_blocks_per_cu(args.blocks_per_cu)
+    for name, val in (("set_gather_width", args.gather_width if args.gather_width >= 0 else None),
+                      ("set_blocks_per_cu", args.blocks_per_cu if args.blocks_per_cu > 0 else None)):
+        if val is not None:
+            (pipe.set_local_option(name, val) if sharded else getattr(local_adj, name)(val))
 
     def barrier():
         if world > 1:

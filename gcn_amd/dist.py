@@ -57,8 +57,10 @@ class RowShardedAdjacency:
         pcol = owner * self.max_rows + (gcol - bounds_t[owner])
         self.local_nnz = e_hi - e_lo
         self.total_nnz = int(rowptr_h[-1])
-        self.local = make_local(local_rowptr, pcol.to(torch.int32), val[e_lo:e_hi].contiguous(),
-                                (self.rows, self.world * self.max_rows))
+        self._local_args = (local_rowptr, pcol.to(torch.int32), val[e_lo:e_hi].contiguous(),
+                            (self.rows, self.world * self.max_rows))
+        self._make_local = make_local
+        self.local = make_local(*self._local_args)
         self._bounds_t = bounds_t
 
     # global [n, k] -> padded [world*max_rows, k]
@@ -87,14 +89,19 @@ class RowShardedAdjacency:
             views = [out_padded[p * self.max_rows: (p + 1) * self.max_rows] for p in range(self.world)]
             return dist.all_gather(views, slot.clone(), group=group, async_op=async_op)
 
-    def layer_async(self, H_padded, out_padded, group=None):
+    def another_local(self):
+        """A second operator over the same row block (own plan, own workspaces) — what lets two
+        SpMMs of this block run on different streams at the same time (PipelinedAggregation)."""
+        return self._make_local(*self._local_args)
+
+    def layer_async(self, H_padded, out_padded, group=None, local=None):
         """Like layer(), but the all-gather is only ENQUEUED (on the communicator's stream, behind
         the SpMM that fills the slot); returns the Work handle (None for world == 1).  The caller
         waits on it before the next read of out_padded — this is what lets the all-gather of one
         column plane overlap the SpMM of the next (PipelinedAggregation)."""
         slot = out_padded[self.rank * self.max_rows: (self.rank + 1) * self.max_rows]
         if self.rows:
-            self.local.matmul_raw(H_padded, out=slot[: self.rows])
+            (local or self.local).matmul_raw(H_padded, out=slot[: self.rows])
         if self.world > 1 and self.collective:
             return self._all_gather(out_padded, slot, group, True)
         return None
@@ -127,12 +134,27 @@ class PipelinedAggregation:
     is also the kernel's preferred column tile when n·256 B fits the Infinity Cache.
     """
 
-    def __init__(self, shard, k, device, plane_cols=64, group=None):
+    def __init__(self, shard, k, device, plane_cols=64, group=None, streams=None):
         self.shard, self.k, self.group = shard, int(k), group
         self.widths = [min(plane_cols, k - c) for c in range(0, k, plane_cols)]
         self.src = [shard.new_buffer(w, device) for w in self.widths]
         self.dst = [shard.new_buffer(w, device) for w in self.widths]
         self.pending = [None] * len(self.widths)
+        # One HIP stream and one operator (plan + workspaces) per plane: the planes' chains
+        # (SpMM passes -> fix-up -> slice reduction -> all-gather) are independent, so on separate
+        # streams the short tail kernels and launch gaps of one plane hide under the main kernel of the
+        # other (rank-0 share of an 8-way partition of the Reddit-shaped graph, compute only: 0.546 ->
+        # 0.501 ms per layer, profiles/r01f_sim8_streams.log).  Off on the CPU (gloo tests) and for a single plane.
+        dev = torch.device(device)
+        if streams is None:
+            streams = dev.type == "cuda" and len(self.widths) > 1
+        self.streams = [torch.cuda.Stream(dev) for _ in self.widths] if streams else None
+        self.locals = [shard.local] + [shard.another_local() if streams else shard.local for _ in self.widths[1:]]
+
+    def set_local_option(self, name, *args):
+        """apply a CsrAdjacency setter (set_blocks_per_cu, set_gather_width, ...) to every plane's operator"""
+        for loc in {id(l): l for l in self.locals}.values():
+            getattr(loc, name)(*args)
 
     def load(self, H):
         """global [n, k] features → the planes' source buffers"""
@@ -141,16 +163,35 @@ class PipelinedAggregation:
             self.src[p].copy_(self.shard.to_padded(H[:, c:c + w].contiguous()))
             c += w
 
+    def _one_plane(self, p):
+        if self.pending[p] is not None:
+            self.pending[p].wait()                  # the gather that produced src[p]
+            self.pending[p] = None
+        self.pending[p] = self.shard.layer_async(self.src[p], self.dst[p], self.group, local=self.locals[p])
+        self.src[p], self.dst[p] = self.dst[p], self.src[p]
+
     def step(self):
         """one aggregation layer over all planes (all-gathers left in flight)"""
-        for p in range(len(self.widths)):
-            if self.pending[p] is not None:
-                self.pending[p].wait()              # the gather that produced src[p]
-                self.pending[p] = None
-            self.pending[p] = self.shard.layer_async(self.src[p], self.dst[p], self.group)
-            self.src[p], self.dst[p] = self.dst[p], self.src[p]
+        if self.streams is None:
+            for p in range(len(self.widths)):
+                self._one_plane(p)
+            return
+        cur = torch.cuda.current_stream()
+        for p, s in enumerate(self.streams):
+            s.wait_stream(cur)                      # whatever filled src[p] on the caller's stream
+            with torch.cuda.stream(s):
+                self._one_plane(p)
 
     def finish(self):
+        if self.streams is not None:
+            cur = torch.cuda.current_stream()
+            for p, s in enumerate(self.streams):
+                with torch.cuda.stream(s):
+                    if self.pending[p] is not None:
+                        self.pending[p].wait()
+                        self.pending[p] = None
+                cur.wait_stream(s)
+            return
         for p, w in enumerate(self.pending):
             if w is not None:
                 w.wait()
