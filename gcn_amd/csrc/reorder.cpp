@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <map>
 #include <ranges>
+#include <thread>
 #include <utility>
 
 namespace gcn {
@@ -596,14 +597,36 @@ void csr_apply_rank(int32_t* rowptr, int32_t* col, float* vals, int64_t n, int64
   std::vector<float> nval(nnz);
   for (int64_t u = 0; u < n; ++u) nrow[rank[u] + 1] = rowptr[u + 1] - rowptr[u];
   for (int64_t i = 0; i < n; ++i) nrow[i + 1] += nrow[i];
-  std::vector<std::pair<float, unsigned int>> row;
-  for (int64_t u = 0; u < n; ++u) {
-    row.clear();
-    for (int32_t e = rowptr[u]; e < rowptr[u + 1]; ++e)
-      row.emplace_back(vals[e], (unsigned int)rank[col[e]]);
-    std::ranges::sort(row, std::ranges::less(), [](auto& p) { return p.second; });
-    int32_t o = nrow[rank[u]];
-    for (auto& [val, c] : row) { ncol[o] = (int32_t)c; nval[o++] = val; }
+  // rows are independent (each writes its own range of the output), so the per-row sorts run on all
+  // host cores; the result does not depend on the thread count
+  auto rows = [&](int64_t lo, int64_t hi) {
+    std::vector<std::pair<float, unsigned int>> row;
+    for (int64_t u = lo; u < hi; ++u) {
+      row.clear();
+      for (int32_t e = rowptr[u]; e < rowptr[u + 1]; ++e)
+        row.emplace_back(vals[e], (unsigned int)rank[col[e]]);
+      std::ranges::sort(row, std::ranges::less(), [](auto& p) { return p.second; });
+      int32_t o = nrow[rank[u]];
+      for (auto& [val, c] : row) { ncol[o] = (int32_t)c; nval[o++] = val; }
+    }
+  };
+  unsigned nt = std::thread::hardware_concurrency();
+  if (nt > 64) nt = 64;
+  if (nt < 2 || nnz < (1 << 18)) {
+    rows(0, n);
+  } else {
+    // equal shares of the non-zeros, not of the rows
+    std::vector<std::thread> pool;
+    int64_t lo = 0;
+    for (unsigned t = 0; t < nt; ++t) {
+      const int64_t target = nnz / nt * (t + 1);
+      int64_t hi = (t + 1 == nt) ? n : (int64_t)(std::upper_bound(rowptr, rowptr + n + 1, (int32_t)target) - rowptr) - 1;
+      if (hi < lo) hi = lo;
+      if (hi > n) hi = n;
+      pool.emplace_back(rows, lo, hi);
+      lo = hi;
+    }
+    for (auto& th : pool) th.join();
   }
   std::copy(nrow.begin(), nrow.end(), rowptr);
   std::copy(ncol.begin(), ncol.end(), col);
