@@ -148,6 +148,38 @@ class CsrAdjacency:
         """main-kernel launches (column passes) one k-wide SpMM issues"""
         return int(_lib.load().gcn_spmm_plan_num_passes(self.plan, int(k)))
 
+    def autotune(self, k=128, reps=3, verbose=False):
+        """Measure, don't guess: time a k-wide SpMM with and without XCD column slicing on this matrix
+        and keep the faster configuration.  The automatic rule (auto_slices) is derived from unordered
+        graphs; a matrix whose rows were renumbered to sit near their neighbours (Rabbit, RCM on a graph
+        with communities) can be faster unsliced.  → dict {slices: ms}, chosen first."""
+        B = torch.randn((self.n, int(k)), dtype=torch.float32, device=self.device)
+        out = torch.empty((self.m, int(k)), dtype=torch.float32, device=self.device)
+        tried = {}
+        for S in (-1, 8, 0):                                  # the automatic count, one slice per XCD, none
+            try:
+                self.enable_slicing(S)
+            except _lib.GcnAmdError:
+                continue                                       # (unsorted rows, S*m too large, ...)
+            eff = self.num_slices
+            if eff in tried:
+                continue
+            for _i in range(2):
+                self.matmul_raw(B, out=out)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _i in range(reps):
+                self.matmul_raw(B, out=out)
+            e1.record()
+            torch.cuda.synchronize(self.device)
+            tried[eff] = e0.elapsed_time(e1) / reps
+            if verbose:
+                print(f"autotune: slices={eff}: {tried[eff]:.4f} ms")
+        best = min(tried, key=tried.get)
+        self.enable_slicing(best)
+        self.slices = best
+        return dict(sorted(tried.items(), key=lambda kv: kv[1]))
+
     def main_kernel(self, k, epilogue=False):
         """name of the main kernel a k-wide SpMM on this plan launches (as rocprofv3 prints it)"""
         buf = ctypes.create_string_buffer(128)

@@ -597,3 +597,17 @@ def test_panels_with_everything_staged_and_with_nothing_staged():
     adj2 = _adj(rp2, ci2, va2, m2, n2, panels=1)
     assert adj2.panel_coverage < 0.05
     assert rel_err(adj2.matmul_raw(torch.from_numpy(B2).to(d)).cpu().numpy(), oracle_spmm(rp2, ci2, va2, B2)) <= TOL
+
+
+def test_autotune_keeps_the_faster_of_sliced_and_unsliced_and_the_result():
+    """CsrAdjacency.autotune measures both configurations on the matrix itself; whatever it keeps,
+    the product is the same"""
+    rowptr, col, val, n = graphgen.make_sbm(30000, device="cuda:0", seed=7)
+    adj = gcn_amd.CsrAdjacency(rowptr, col, val, (n, n), symmetric=True)
+    B = graphgen.random_features(n, 128, seed=3, device="cuda:0")
+    before = adj.matmul_raw(B).clone()
+    timings = adj.autotune(k=128)
+    assert len(timings) >= 2 and 0 in timings and all(t > 0 for t in timings.values())
+    assert adj.num_slices == next(iter(timings))              # the fastest one stays configured
+    after = adj.matmul_raw(B)
+    assert float((after - before).abs().max() / before.abs().max()) <= 1e-6
