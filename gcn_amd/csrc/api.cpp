@@ -53,6 +53,9 @@ struct gcn_spmm_plan {
   float* pout_val;
   int* pout_chunk_row;
   int pout_nnz, pout_T, pout_nchunks;
+  int pout_S;                   // column slices of the out-of-window part (0: unsliced)
+  int *pout_vrowptr, *pout_vcol, *pout_vchunk_row;
+  float* pout_vval;
 };
 
 namespace {
@@ -253,7 +256,7 @@ int gcn_spmm_plan_destroy(gcn_spmm_plan_t* p) {
   if (p->cpad) (void)hipFree(p->cpad);
   {
     void* ptrs[] = {p->panel_w0, p->pin_rowptr, p->pin_off, p->pin_val, p->pout_rowptr, p->pout_col,
-                    p->pout_val, p->pout_chunk_row};
+                    p->pout_val, p->pout_chunk_row, p->pout_vrowptr, p->pout_vcol, p->pout_vchunk_row, p->pout_vval};
     for (void* q : ptrs) if (q) (void)hipFree(q);
   }
   for (auto& e : p->ev) (void)hipEventDestroy(e);
@@ -361,13 +364,25 @@ static int spmm_impl(gcn_spmm_plan_t* p, const int32_t* rowptr, const int32_t* c
       if (ev1 && hipEventRecord(ev1, st) != hipSuccess) return GCN_ERR_HIP;
       return GCN_OK;
     }
-    a.rowptr = p->pout_rowptr; a.col = p->pout_col; a.val = p->pout_val;
-    a.chunk_row = p->pout_chunk_row; a.nchunks = p->pout_nchunks; a.nchunks_grid = p->pout_nchunks;
-    a.T = p->pout_T; a.nnz = p->pout_nnz; a.accumulate = 1;
-    a.tile_cols = p->tile_cols ? p->tile_cols : auto_tile_cols(p->n, k);
+    a.nchunks = p->pout_nchunks; a.nchunks_grid = p->pout_nchunks;
+    a.T = p->pout_T; a.nnz = p->pout_nnz;
     a.blocks_per_cu = p->blocks_per_cu;
     a.gather_width = p->gather_width;
     a.ev_start = nullptr; a.ev_stop = ev1;
+    if (p->pout_S > 0) {
+      // sliced: partial rows of the virtual CSR, then C += sum of the partials (+ epilogue)
+      const int st2 = grow(p->cv, p->cv_bytes, sizeof(float) * (size_t)p->pout_S * (size_t)p->m * (size_t)k);
+      if (st2 != GCN_OK) return st2;
+      a.rowptr = p->pout_vrowptr; a.col = p->pout_vcol; a.val = p->pout_vval; a.chunk_row = p->pout_vchunk_row;
+      a.C = p->cv; a.m = p->pout_S * p->m; a.bias = nullptr; a.relu = 0; a.accumulate = 0;
+      a.tile_cols = p->tile_cols ? p->tile_cols : 64;
+      if (gcn::launch_spmm(a, p->cu_count, st) != hipSuccess) return GCN_ERR_HIP;
+      return gcn::launch_slice_reduce(p->cv, C, bias, relu ? 1 : 0, p->m, p->pout_S, k, st, 1) == hipSuccess
+                 ? GCN_OK : GCN_ERR_HIP;
+    }
+    a.rowptr = p->pout_rowptr; a.col = p->pout_col; a.val = p->pout_val;
+    a.chunk_row = p->pout_chunk_row; a.accumulate = 1;
+    a.tile_cols = p->tile_cols ? p->tile_cols : auto_tile_cols(p->n, k);
     return gcn::launch_spmm(a, p->cu_count, st) == hipSuccess ? GCN_OK : GCN_ERR_HIP;
   }
   a.tile_cols = p->tile_cols ? p->tile_cols : (sliced ? 64 : auto_tile_cols(p->n, k));
@@ -450,11 +465,12 @@ int32_t gcn_spmm_plan_num_slices(const gcn_spmm_plan_t* p) { return p ? p->S : -
 
 static void free_panels(gcn_spmm_plan* p) {
   void* ptrs[] = {p->panel_w0, p->pin_rowptr, p->pin_off, p->pin_val, p->pout_rowptr, p->pout_col,
-                  p->pout_val, p->pout_chunk_row};
+                  p->pout_val, p->pout_chunk_row, p->pout_vrowptr, p->pout_vcol, p->pout_vchunk_row, p->pout_vval};
   for (void* q : ptrs) if (q) (void)hipFree(q);
   p->panel_w0 = p->pin_rowptr = p->pin_off = p->pout_rowptr = p->pout_col = p->pout_chunk_row = nullptr;
-  p->pin_val = p->pout_val = nullptr;
-  p->panel_R = 0; p->pout_nnz = p->pout_T = p->pout_nchunks = 0;
+  p->pout_vrowptr = p->pout_vcol = p->pout_vchunk_row = nullptr;
+  p->pin_val = p->pout_val = p->pout_vval = nullptr;
+  p->panel_R = 0; p->pout_nnz = p->pout_T = p->pout_nchunks = p->pout_S = 0;
 }
 
 int gcn_spmm_plan_enable_panels(gcn_spmm_plan_t* p, const int32_t* rowptr, const int32_t* col,
@@ -503,6 +519,29 @@ int gcn_spmm_plan_enable_panels(gcn_spmm_plan_t* p, const int32_t* rowptr, const
     }
     if (gcn::launch_plan_chunk_rows(p->pout_rowptr, p->m, p->pout_T, p->pout_nchunks, p->pout_chunk_row,
                                     st) != hipSuccess) { free_panels(p); return GCN_ERR_HIP; }
+  }
+  // The out-of-window part is what is LEFT of the matrix once the local structure is staged: short
+  // rows with columns all over the range, i.e. an unordered graph — the case XCD column slicing is
+  // for (slicing.hip).  Measured on the 240 k-vertex planted-partition graph (22 M left-over entries,
+  // 92 per row): slicing them 8-ways cuts the gather time only with the one-per-gather kernel (virtual
+  // rows of 11 entries: 2.49 -> 2.07 ms of kernels) and then pays 0.23 ms for the reduction — no clear
+  // win, so it stays off unless GCN_AMD_PANEL_OUT_SLICES asks for it.
+  static const int out_slices = [] { const char* v = std::getenv("GCN_AMD_PANEL_OUT_SLICES"); return v ? std::atoi(v) : 0; }();
+  const int S = out_slices;
+  if (S > 1 && p->pout_nchunks > 0 && (long long)S * p->m + 1 < (1LL << 31)) {
+    const long long vm = (long long)S * p->m;
+    if (hipMalloc((void**)&p->pout_vrowptr, sizeof(int) * (size_t)(vm + 1)) != hipSuccess ||
+        hipMalloc((void**)&p->pout_vcol, sizeof(int) * (size_t)nnz_out) != hipSuccess ||
+        hipMalloc((void**)&p->pout_vval, sizeof(float) * (size_t)nnz_out) != hipSuccess ||
+        hipMalloc((void**)&p->pout_vchunk_row, sizeof(int) * (size_t)p->pout_nchunks) != hipSuccess) {
+      free_panels(p); return GCN_ERR_ALLOC;
+    }
+    int sorted = 1;
+    if (gcn::build_sliced_csr(p->pout_rowptr, p->pout_col, p->pout_val, p->m, p->n, nnz_out, S, p->pout_vrowptr,
+                              p->pout_vcol, p->pout_vval, &sorted, st) != hipSuccess) { free_panels(p); return GCN_ERR_HIP; }
+    if (sorted && gcn::launch_plan_chunk_rows(p->pout_vrowptr, (int)vm, p->pout_T, p->pout_nchunks,
+                                              p->pout_vchunk_row, st) != hipSuccess) { free_panels(p); return GCN_ERR_HIP; }
+    if (sorted) p->pout_S = S;                 // (unsorted rows: the unsliced out-of-window pass stays)
   }
   p->panel_R = R;
   return GCN_OK;

@@ -81,11 +81,11 @@ slice_scatter_kernel(const int* __restrict__ rowptr, const int* __restrict__ col
   }
 }
 
-// C[r, :] = act( sum_s Cv[s*m + r, :] + bias ), partials added in slice order; wave per row
+// C[r, :] = act( [C[r, :] +] sum_s Cv[s*m + r, :] + bias ), partials added in slice order; wave per row
 template <int VEC>
 __global__ void __launch_bounds__(256)
 slice_reduce_kernel(const float* __restrict__ Cv, float* __restrict__ C,
-                    const float* __restrict__ bias, int relu, int m, int S, int k) {
+                    const float* __restrict__ bias, int relu, int m, int S, int k, int accumulate) {
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int nw = gridDim.x * 4;
@@ -94,6 +94,11 @@ slice_reduce_kernel(const float* __restrict__ Cv, float* __restrict__ C,
       float acc[VEC];
 #pragma unroll
       for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+      if (accumulate) {                             // C already holds another part of the product
+        const float* o = C + (size_t)r * (size_t)k + x;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i] = o[i];
+      }
       for (int s = 0; s < S; ++s) {
         const float* p = Cv + ((size_t)s * m + r) * (size_t)k + x;
         if (VEC == 4) {
@@ -174,13 +179,13 @@ hipError_t build_sliced_csr(const int* rowptr, const int* col, const float* val,
 }
 
 hipError_t launch_slice_reduce(const float* Cv, float* C, const float* bias, int relu, int m, int S,
-                               int k, hipStream_t st) {
+                               int k, hipStream_t st, int accumulate) {
   if (m <= 0 || k <= 0) return hipSuccess;
   int nb = (m + 3) / 4;
   if (nb > 8192) nb = 8192;
   const uintptr_t al = (uintptr_t)Cv | (uintptr_t)C | (uintptr_t)bias;
-  if (k % 4 == 0 && (al & 15) == 0) slice_reduce_kernel<4><<<nb, 256, 0, st>>>(Cv, C, bias, relu, m, S, k);
-  else                              slice_reduce_kernel<1><<<nb, 256, 0, st>>>(Cv, C, bias, relu, m, S, k);
+  if (k % 4 == 0 && (al & 15) == 0) slice_reduce_kernel<4><<<nb, 256, 0, st>>>(Cv, C, bias, relu, m, S, k, accumulate);
+  else                              slice_reduce_kernel<1><<<nb, 256, 0, st>>>(Cv, C, bias, relu, m, S, k, accumulate);
   return hipGetLastError();
 }
 

@@ -83,6 +83,6 @@ hipError_t build_sliced_csr(const int* rowptr, const int* col, const float* val,
                             int nnz, int S, int* vrowptr, int* vcol, float* vval,
                             int* sorted_out, hipStream_t st);
 hipError_t launch_slice_reduce(const float* Cv, float* C, const float* bias, int relu, int m, int S,
-                               int k, hipStream_t st);
+                               int k, hipStream_t st, int accumulate = 0);
 
 }  // namespace gcn

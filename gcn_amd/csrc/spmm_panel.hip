@@ -25,6 +25,7 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 #include <stdint.h>
+#include <stdlib.h>
 #include "spmm_kernels.h"
 
 namespace gcn {
@@ -235,6 +236,128 @@ spmm_panel_in_kernel(const int* __restrict__ in_rowptr, const int* __restrict__ 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same staged sum with FOUR entries per LDS instruction (k % 4 == 0): lane = sub*16 + f reads
+// 16 bytes (ds_read_b128) of the staged row of entry (step, sub) — conflict-free whatever the four
+// rows are, because a 256-byte row covers every bank exactly once and the b128 lane groups take
+// disjoint quarters of it — after a DPP row broadcast of the entry's (offset, value) from the
+// transposed 64-entry block (exactly the layout of spmm_quad.hip).  Per 4 entries: 2 DPP moves, one
+// address add, one ds_read_b128, two packed FMAs; the first version above needs 4 x (2 v_readlane +
+// add + ds_read_b32 + FMA) and ran at the same 62 G entries/s as the L2 gather path.
+// ---------------------------------------------------------------------------------------------
+template <int UU>
+__device__ __forceinline__ int panel_bcast(int v) {
+  return __builtin_amdgcn_mov_dpp(v, 0x150 + UU, 0xf, 0xf, true);              // row_newbcast:UU
+}
+
+__global__ void __launch_bounds__(PANEL_WAVES * 64)
+spmm_panel_in_quad_kernel(const int* __restrict__ in_rowptr, const int* __restrict__ in_off,
+                          const float* __restrict__ in_val, const float* __restrict__ B,
+                          float* __restrict__ C, const int* __restrict__ panel_w0,
+                          int m, int n, int k, int R, int col_tile) {
+  extern __shared__ float lds[];                    // [PANEL_W][64] tile + [PANEL_WAVES][16] float4 scratch
+  const char* tile = reinterpret_cast<const char*>(lds);
+  float4* scratch = reinterpret_cast<float4*>(lds + PANEL_W * 64);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = psgpr(tid >> 6);
+  const int sub = lane >> 4, f = lane & 15;
+  const int tl = f * 4 + sub;                       // transposed position this lane loads
+  const int r0 = blockIdx.x * R;
+  const int r1 = min(m, r0 + R);
+  const int w0 = panel_w0[blockIdx.x];
+  const int wn = min(PANEL_W, n - w0);
+  const int fcol = col_tile * 64 + f * 4;
+  const bool writer = fcol < k && sub == 0;
+  const size_t kk = (size_t)k;
+  const int foff = f * 16;
+
+  // ---- stage the window's feature tile (columns past k are zero-filled) ----
+  for (int i0 = tid; i0 < wn * 64; i0 += PANEL_WAVES * 64 * 8) {
+    float t[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int i = i0 + q * PANEL_WAVES * 64;
+      const int rr = i >> 6, cc = col_tile * 64 + (i & 63);
+      t[q] = (i < wn * 64 && cc < k) ? B[(size_t)(w0 + rr) * kk + cc] : 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int i = i0 + q * PANEL_WAVES * 64;
+      if (i < wn * 64) lds[i] = t[q];
+    }
+  }
+  __syncthreads();
+
+  // this lane's (sub, f) partial over the staged entries [beg, end), 64-entry blocks `stride` apart
+  auto row_sum = [&](int beg, int end, int first, int stride) -> float4 {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    int base = beg + first * 64;
+    int oj_nx = 0;
+    float vj_nx = 0.f;
+    if (base + tl < end) { oj_nx = in_off[base + tl]; vj_nx = in_val[base + tl]; }
+    for (; base < end; base += stride * 64) {
+      const int cnt = min(64, end - base);
+      const int oj = oj_nx;
+      const int vji = __builtin_bit_cast(int, vj_nx);
+      const int nb = base + stride * 64;
+      oj_nx = 0; vj_nx = 0.f;
+      if (nb + tl < end) { oj_nx = in_off[nb + tl]; vj_nx = in_val[nb + tl]; }
+      float4 b[16];
+#define GCN_P_READ(UU) b[UU] = *reinterpret_cast<const float4*>(tile + panel_bcast<UU>(oj) + foff);
+#define GCN_P_ALL(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15)
+      GCN_P_ALL(GCN_P_READ)                          // entries past cnt carry offset 0: row 0 of the tile, masked below
+      if (cnt == 64) {
+#define GCN_P_FMA(UU) { const float v = __builtin_bit_cast(float, panel_bcast<UU>(vji));           \
+          acc.x = fmaf(v, b[UU].x, acc.x); acc.y = fmaf(v, b[UU].y, acc.y);                        \
+          acc.z = fmaf(v, b[UU].z, acc.z); acc.w = fmaf(v, b[UU].w, acc.w); }
+        GCN_P_ALL(GCN_P_FMA)
+#undef GCN_P_FMA
+      } else {                                       // the row's last block: mask on the product
+#define GCN_P_TAIL(UU) { const bool in = UU * 4 + sub < cnt;                                       \
+          const float v = __builtin_bit_cast(float, panel_bcast<UU>(vji));                         \
+          acc.x = in ? fmaf(v, b[UU].x, acc.x) : acc.x; acc.y = in ? fmaf(v, b[UU].y, acc.y) : acc.y; \
+          acc.z = in ? fmaf(v, b[UU].z, acc.z) : acc.z; acc.w = in ? fmaf(v, b[UU].w, acc.w) : acc.w; }
+        GCN_P_ALL(GCN_P_TAIL)
+#undef GCN_P_TAIL
+      }
+#undef GCN_P_ALL
+#undef GCN_P_READ
+    }
+    // over the four subs
+    acc.x += __shfl_xor(acc.x, 16); acc.y += __shfl_xor(acc.y, 16);
+    acc.z += __shfl_xor(acc.z, 16); acc.w += __shfl_xor(acc.w, 16);
+    acc.x += __shfl_xor(acc.x, 32); acc.y += __shfl_xor(acc.y, 32);
+    acc.z += __shfl_xor(acc.z, 32); acc.w += __shfl_xor(acc.w, 32);
+    return acc;
+  };
+
+  // ---- ordinary rows: one wave per row ----
+  for (int r = r0 + w; r < r1; r += PANEL_WAVES) {
+    const int beg = in_rowptr[r], end = in_rowptr[r + 1];
+    if (end - beg > PANEL_LONG_ROW) continue;
+    const float4 acc = row_sum(beg, end, 0, 1);
+    if (writer) *reinterpret_cast<float4*>(C + (size_t)r * kk + fcol) = acc;
+  }
+  // ---- hub rows: all waves together, partials combined through LDS in wave order ----
+  for (int r = r0; r < r1; ++r) {
+    const int beg = in_rowptr[r], end = in_rowptr[r + 1];
+    if (end - beg <= PANEL_LONG_ROW) continue;
+    const float4 part = row_sum(beg, end, w, PANEL_WAVES);
+    __syncthreads();                                 // scratch free again
+    if (sub == 0) scratch[w * 16 + f] = part;
+    __syncthreads();
+    if (w == 0) {
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int i = 0; i < PANEL_WAVES; ++i) {
+        const float4 t = scratch[i * 16 + f];
+        acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+      }
+      if (writer) *reinterpret_cast<float4*>(C + (size_t)r * kk + fcol) = acc;
+    }
+  }
+}
+
 // C = act(C + bias): the epilogue alone, for when the out-of-window part is empty
 __global__ void panel_epilogue_kernel(float* __restrict__ C, const float* __restrict__ bias, int relu,
                                       long long total, int k) {
@@ -315,12 +438,21 @@ hipError_t launch_panel_in(const int* in_rowptr, const int* in_off, const float*
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_panel_in_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_panel_in_quad_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
     attr_done = true;
   }
   const int panels = (m + R - 1) / R;
-  spmm_panel_in_kernel<<<dim3(panels), dim3(PANEL_WAVES * 64), lds_bytes, s>>>(
-      in_rowptr, in_off, in_val, B, C, panel_w0, m, n, k, R, tile);
+  static const bool quad_on = [] { const char* v = getenv("GCN_AMD_PANEL_QUAD"); return !v || v[0] != '0'; }();
+  // four entries per LDS instruction when rows of C can take 16-byte stores
+  if (quad_on && k % 4 == 0 && ((uintptr_t)C & 15) == 0)
+    spmm_panel_in_quad_kernel<<<dim3(panels), dim3(PANEL_WAVES * 64), lds_bytes, s>>>(
+        in_rowptr, in_off, in_val, B, C, panel_w0, m, n, k, R, tile);
+  else
+    spmm_panel_in_kernel<<<dim3(panels), dim3(PANEL_WAVES * 64), lds_bytes, s>>>(
+        in_rowptr, in_off, in_val, B, C, panel_w0, m, n, k, R, tile);
   return hipGetLastError();
 }
 
