@@ -147,6 +147,15 @@ static int slice_min_k() {
   return v;
 }
 
+// the four-per-gather kernel only pays from ~48 non-zeros per (virtual) row up (use_quad in
+// spmm_kernels.hip); the odd-width path exists to reach that kernel, so it follows the same rule
+static bool rows_long_enough_for_quad(const gcn_spmm_plan* p, int k) {
+  if (p->gather_width == 4) return true;
+  const bool sliced = p->S > 0 && k >= slice_min_k();
+  const long long rows = sliced ? (long long)p->S * p->m : (long long)p->m;
+  return rows > 0 && p->nnz / rows >= 48;
+}
+
 // Number of column slices for the XCD-aware slicing (slicing.hip), 0 = do not slice.
 // Measured on MI355X with the r01f kernels (profiles/r01f_sweep_slices_scales.log; Reddit-shaped graphs
 // of 14.5 k .. 1.86 M vertices, mean degree 493; whole SpMM, k = 128, best S in brackets):
@@ -298,7 +307,8 @@ int gcn_spmm_csr_f32_bias_relu(gcn_spmm_plan_t* p, const int32_t* rowptr, const 
   // B re-laid with zero columns (stride a multiple of 32 floats), the product into a k'-wide scratch
   // result, and one pass that compacts it into C (and applies the epilogue).  Reddit-shaped k = 41:
   // 2.13 -> 1.87 ms.  Same limits as the B padding above (tables <= 768 MiB), panels excluded.
-  if (k > 16 && k % 4 != 0 && p->nnz > 0 && p->panel_R == 0 && p->gather_width != 1 && pad_b_enabled()) {
+  if (k > 16 && k % 4 != 0 && p->nnz > 0 && p->panel_R == 0 && p->gather_width != 1 && pad_b_enabled() &&
+      rows_long_enough_for_quad(p, k)) {
     const int kp = (k + 3) / 4 * 4, ldb = (kp + 31) / 32 * 32;
     if ((long long)sizeof(float) * p->n * ldb <= (768LL << 20)) {
       int st = grow(p->bpad, p->bpad_bytes, sizeof(float) * (size_t)p->n * (size_t)ldb);
@@ -581,13 +591,13 @@ int gcn_spmm_plan_main_kernel(const gcn_spmm_plan_t* p, int32_t k, int32_t epilo
   if (p->panel_R > 0 && k > 32) { snprintf(buf, (size_t)buflen, "gcn::spmm_panel_in_kernel"); return GCN_OK; }
   gcn::SpmmArgs a{};
   const bool sliced = p->S > 0 && p->nnz > 0 && k >= slice_min_k();
-  a.k = k; a.n = p->n; a.m = sliced ? p->S * p->m : p->m;
+  a.k = k; a.n = p->n; a.m = sliced ? p->S * p->m : p->m; a.nnz = p->nnz;
   a.nchunks_grid = p->nchunks;
   a.relu = epilogue && !sliced ? 1 : 0;               // sliced: the epilogue runs in the slice reduction
   a.tile_cols = p->tile_cols ? p->tile_cols : (sliced ? 64 : auto_tile_cols(p->n, k));
   a.gather_width = p->gather_width;
   if (k > 16 && k % 4 != 0 && p->panel_R == 0 && p->gather_width != 1 && pad_b_enabled() &&
-      (long long)sizeof(float) * p->n * (((k + 3) / 4 * 4 + 31) / 32 * 32) <= (768LL << 20)) {
+      rows_long_enough_for_quad(p, k) && (long long)sizeof(float) * p->n * (((k + 3) / 4 * 4 + 31) / 32 * 32) <= (768LL << 20)) {
     a.k = (k + 3) / 4 * 4;                             // odd widths run at k rounded up to 4 (see gcn_spmm_csr_f32_bias_relu)
     a.ldb = (a.k + 31) / 32 * 32;
     a.relu = 0;

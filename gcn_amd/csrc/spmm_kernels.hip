@@ -391,10 +391,18 @@ int pick_vec(int k, int tile_cols, const void* B, const void* C, const void* P) 
 
 // the quad kernel (spmm_quad.hip) runs whenever its layout applies: k % 4 == 0, 16-byte aligned operands,
 // 32-bit byte offsets; for k > 32 only where the 64-column tile is the chosen tile width
+constexpr int kQuadMinRowLen = 48;
+
 static bool use_quad(const SpmmArgs& a) {
   static const bool quad_on = [] { const char* v = getenv("GCN_AMD_QUAD"); return !v || v[0] != '0'; }();
   static const int min_k = [] { const char* v = getenv("GCN_AMD_QUAD_MIN_K"); return v ? atoi(v) : 12; }();
   if (!quad_on || a.gather_width == 1 || a.k < min_k || !spmm_quad_eligible(a)) return false;
+  // Short rows: every finished row costs the quad layout a cross-lane reduction (8-16 shuffles) where
+  // the one-per-gather kernel just stores.  R-MAT, n = 1 M, k = 64 (profiles/r01f_lowdeg_probe.log), one-
+  // vs four-per-gather: mean degree 4.9: 0.229 vs 0.508 ms; 8.8: 0.33 vs 0.56; 16: 0.54 vs 0.64;
+  // 31: 0.87 vs 0.89; 59: 1.573 vs 1.564 -> the quad kernel from ~48 non-zeros per (virtual) row up.
+  const long long nnz = a.nnz_dev ? (long long)a.nchunks_grid * a.T : (long long)a.nnz;
+  if (a.gather_width != 4 && a.m > 0 && nnz / a.m < kQuadMinRowLen) return false;
   return a.k <= 32 || pick_vec(a.k, a.tile_cols, a.B, a.C, a.P) == 1;
 }
 

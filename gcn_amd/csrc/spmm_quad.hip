@@ -181,8 +181,8 @@ spmm_quad_kernel(const int* __restrict__ g_rowptr, const int* __restrict__ g_col
         pos += 64;
         while (pos == row_end) flush();
       } else {
-        // rows end inside this block (or it is the ragged last block): one pass over the steps
-        // per row segment [q0, q1) of the block, each lane adding only the products of its own
+        // rows end inside this block (or it is the ragged last block): one pass over the steps that
+        // overlap it per row segment [q0, q1) of the block, each lane adding only the products of its own
         // non-zeros that lie in the segment (masked on the product, so a NaN/Inf in a feature row
         // never leaks into a row of A that does not reference it)
         int q0 = 0;
@@ -190,7 +190,7 @@ spmm_quad_kernel(const int* __restrict__ g_rowptr, const int* __restrict__ g_col
           const int q1 = row_end < 0 ? cnt : min(cnt, row_end - base);
           const unsigned lo = (unsigned)(q0 - sub), len = (unsigned)(q1 - q0);
 #define GCN_Q_SEG(UU)                                                                            \
-          if constexpr (UU < LPE) {                                                              \
+          if constexpr (UU < LPE) if (UU * EPS < q1 && (UU + 1) * EPS > q0) {   /* step overlaps the segment (scalar test) */ \
             const bool in = (unsigned)(UU * EPS) - lo < len;      /* entry UU*EPS + sub in [q0, q1) */ \
             const float v = GCN_Q_VAL(UU);                                                       \
             acc.x = in ? fmaf(v, b[UU].x, acc.x) : acc.x; acc.y = in ? fmaf(v, b[UU].y, acc.y) : acc.y; \

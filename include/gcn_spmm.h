@@ -96,10 +96,13 @@ int gcn_spmm_plan_set_tile_cols(gcn_spmm_plan_t* plan, int32_t cols);
  * and registers free so that a kernel on another stream — the RCCL all-gather of the multi-GPU
  * path — can run beside the SpMM instead of behind it. */
 int gcn_spmm_plan_set_blocks_per_cu(gcn_spmm_plan_t* plan, int32_t blocks);
-/* Non-zeros per gather instruction of the 64-column-tile kernel: 0 = automatic (4 — 16 lanes x 16 bytes
- * per feature row, spmm_quad.hip — whenever k % 4 == 0, operands are 16-byte aligned, n < 2^24 and
- * n*k*4 < 4 GiB; else 1), 1 = always the one-row-per-instruction kernel (52 VGPRs: leaves more
- * room for a concurrent kernel), 4 = as 0.  Any other value: GCN_ERR_INVALID_ARG. */
+/* Non-zeros per gather instruction of the 64-column-tile kernel: 0 = automatic — 4 (16 lanes x 16 bytes
+ * per feature row, spmm_quad.hip) when k % 4 == 0 (odd widths are rounded up internally), operands are
+ * 16-byte aligned, n < 2^24, n*k*4 < 4 GiB AND rows are long (>= 48 non-zeros per row, or per virtual
+ * row when sliced: every finished row costs that layout a cross-lane reduction), else 1; 1 = always the
+ * one-row-per-instruction kernel (52 VGPRs: leaves more room for a concurrent kernel); 4 = the
+ * four-per-gather kernel wherever its layout applies, whatever the row length.  Any other value:
+ * GCN_ERR_INVALID_ARG. */
 int gcn_spmm_plan_set_gather_width(gcn_spmm_plan_t* plan, int32_t nz_per_gather);
 /* number of main-kernel launches (column passes) one k-wide SpMM issues with the current tile */
 int32_t gcn_spmm_plan_num_passes(const gcn_spmm_plan_t* plan, int32_t k);

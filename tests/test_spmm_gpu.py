@@ -31,10 +31,11 @@ def _adj(rowptr, col, val, m, n, **kw):
                                 torch.from_numpy(val).to(d), (m, n), **kw)
 
 
-def _run(rowptr, col, val, m, n, k, seed=0, **kw):
+def _run(rowptr, col, val, m, n, k, seed=0, gather_width=0, **kw):
     rng = np.random.default_rng(seed + 99)
     B = rng.standard_normal((n, k)).astype(np.float32)
     adj = _adj(rowptr, col, val, m, n, **kw)
+    adj.set_gather_width(gather_width)
     C = adj.matmul_raw(torch.from_numpy(B).to(_dev()))
     torch.cuda.synchronize()
     return C.cpu().numpy(), oracle_spmm(rowptr, col, val, B), adj
@@ -42,11 +43,14 @@ def _run(rowptr, col, val, m, n, k, seed=0, **kw):
 
 # every feature width the reference's launcher distinguishes (flexspmm.cu:510-541: 8, 16, 32,
 # <32, >32) plus the BASELINE widths 128/256/512 and awkward ones (odd, non-multiple of 64)
+# (gather width 0 = automatic: the one-per-gather / narrow kernels on this 20-per-row matrix; 4 = the
+#  four-per-gather kernel forced, which the automatic rule only picks from ~48 non-zeros per row up)
+@pytest.mark.parametrize("width", [0, 4])
 @pytest.mark.parametrize("k", [1, 2, 3, 4, 5, 7, 8, 9, 12, 15, 16, 17, 24, 32, 33, 64, 100, 128, 130, 192, 256, 300, 512])
-def test_parity_feature_widths(k):
+def test_parity_feature_widths(k, width):
     m = n = 3000
     rowptr, col, val = random_csr(m, n, 60000, seed=k)
-    C, Cref, _ = _run(rowptr, col, val, m, n, k, seed=k)
+    C, Cref, _ = _run(rowptr, col, val, m, n, k, seed=k, gather_width=width)
     assert rel_err(C, Cref) <= TOL
 
 
@@ -102,8 +106,9 @@ def test_edge_cases_empty_and_tiny():
     assert rel_err(C, Cref) <= TOL
 
 
+@pytest.mark.parametrize("width", [0, 4])
 @pytest.mark.parametrize("k", [4, 8, 16, 20, 33, 47, 64, 100, 128, 256])       # 20, 47, 100: padded feature rows
-def test_nan_inf_do_not_leak_between_rows(k):
+def test_nan_inf_do_not_leak_between_rows(k, width):
     """a row of B holding Inf/NaN only poisons the output rows that reference it — for every kernel
     family (narrow k <= 16, one-non-zero-per-gather, four-per-gather).  Row 0 is the row the kernels'
     padding lanes gather (ragged last block), row 317 an ordinary one."""
@@ -114,6 +119,7 @@ def test_nan_inf_do_not_leak_between_rows(k):
     B[0, :] = np.inf
     B[317, :] = np.nan
     adj = _adj(rowptr, col, val, m, n)
+    adj.set_gather_width(width)
     C = adj.matmul_raw(torch.from_numpy(B).to(_dev())).cpu().numpy()
     touched = np.array([bool(np.isin([0, 317], col[rowptr[r]:rowptr[r + 1]]).any()) for r in range(m)])
     assert touched.any() and (~touched).any()
@@ -152,7 +158,7 @@ def test_main_kernel_families_are_selected_as_documented():
     """which kernel runs for which feature width (gcn_spmm_plan_main_kernel), so that the parity
     tests above are known to cover every family"""
     m = n = 1000
-    rowptr, col, val = random_csr(m, n, 20000, seed=1)
+    rowptr, col, val = random_csr(m, n, 80000, seed=1)                       # 80 non-zeros per row: long rows
     adj = _adj(rowptr, col, val, m, n)
     assert adj.main_kernel(4).startswith("gcn::spmm_narrow_kernel<4,")
     assert adj.main_kernel(8).startswith("gcn::spmm_narrow_kernel<8,")
@@ -170,6 +176,14 @@ def test_main_kernel_families_are_selected_as_documented():
     assert adj.main_kernel(130).startswith("gcn::spmm_chunk_kernel<1,")      # one non-zero per gather, caller's layout
     assert adj.main_kernel(128).startswith("gcn::spmm_chunk_kernel<1,")
     adj.set_gather_width(0)
+    # short rows (20 per row): the per-row reduction of the four-per-gather layout does not pay
+    rp2, ci2, va2 = random_csr(m, n, 20000, seed=2)
+    short = _adj(rp2, ci2, va2, m, n)
+    assert short.main_kernel(128).startswith("gcn::spmm_chunk_kernel<1,")
+    assert short.main_kernel(16) == "gcn::spmm_narrow16_dpp_kernel<false>"
+    assert short.main_kernel(130).startswith("gcn::spmm_chunk_kernel<1,")    # and no detour over k' = 132
+    short.set_gather_width(4)
+    assert short.main_kernel(128) == "gcn::spmm_quad_kernel<16, false>"
     adj.set_tile_cols(256)
     assert adj.main_kernel(256).startswith("gcn::spmm_chunk_kernel<4,")
     adj.set_tile_cols(128)
