@@ -192,10 +192,10 @@ def main():
         del rowptr, col, val
         torch.cuda.empty_cache()
 
-    for name, val in (("set_gather_width", args.gather_width if args.gather_width >= 0 else None),
-                      ("set_blocks_per_cu", args.blocks_per_cu if args.blocks_per_cu > 0 else None)):
-        if val is not None:
-            (pipe.set_local_option(name, val) if sharded else getattr(local_adj, name)(val))
+    for opt_name, opt_val in (("set_gather_width", args.gather_width if args.gather_width >= 0 else None),
+                              ("set_blocks_per_cu", args.blocks_per_cu if args.blocks_per_cu > 0 else None)):
+        if opt_val is not None:
+            (pipe.set_local_option(opt_name, opt_val) if sharded else getattr(local_adj, opt_name)(opt_val))
 
     def barrier():
         if world > 1:
