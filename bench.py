@@ -271,6 +271,11 @@ def main():
                 "timing": "HIP events recorded by libgcnspmm on the launch stream around the main-kernel "
                           "passes of every timed SpMM (gcn_spmm_profile_begin/_end)",
                 "traffic": traffic,
+                # what the kernel really moves across the XCD <-> memory-side fabric (L2 misses, Infinity-Cache
+                # hits included), as a rate and against the 6.29 TB/s this GPU reaches in a plain copy
+                "traffic_GBps": None if traffic is None or kavg <= 0 else round(traffic / kavg / 1e9, 1),
+                "traffic_frac_of_measured_copy_peak_6.29TBps": None if traffic is None or kavg <= 0
+                else round(traffic / kavg / 6.29e12, 4),
                 "traffic_source": None if traffic is None else
                 "profiles/pmc_latest.json (separate rocprofv3 --pmc passes; FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; "
                 "L2-miss bytes incl. Infinity-Cache hits)",
