@@ -18,7 +18,11 @@ import os
 import sys
 import time
 
-import torch
+# the host driver of this pool only supports dmabuf IPC: RCCL / device-tensor sharing across processes needs
+# this before the HIP runtime starts (it is exported on the boxes already; kept here so a bare launch works)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
