@@ -90,3 +90,39 @@ def load_graphsaint(prefix, normalize=True):
             labels[k] = v
     return dict(adj=adj_full, adj_train=adj_train, features=feats, labels=labels,
                 idx_train=np.array(role["tr"]), idx_val=np.array(role["va"]), idx_test=np.array(role["te"]))
+
+
+def load_deeprobust_npz(path, require_lcc=True):
+    """DeepRobust-style dataset file (cora.npz, citeseer.npz, … — what dataio.py:128-150 opens and
+    :106-126 post-processes): CSR triplets `adj_*`, optional `attr_*`, optional `labels`.
+    → (adj, features, labels): adj symmetrised, unweighted, zero diagonal, fp32 CSR, restricted to the
+    largest connected component when asked (ties between equally large components go to the one scipy
+    numbers last, as the reference's reversed argsort does); features fp32 CSR (identity when the file
+    has none).  Loaded with numpy's pickle-free reader."""
+    with np.load(path, allow_pickle=False) as z:
+        adj = sp.csr_matrix((z["adj_data"], z["adj_indices"], z["adj_indptr"]), shape=tuple(z["adj_shape"]))
+        if "attr_data" in z.files:
+            feats = sp.csr_matrix((z["attr_data"], z["attr_indices"], z["attr_indptr"]), shape=tuple(z["attr_shape"]))
+        else:
+            feats = sp.identity(adj.shape[0], format="csr")
+        labels = z["labels"] if "labels" in z.files else None
+    feats = sp.csr_matrix(feats, dtype=np.float32)
+    adj = (adj + adj.T).tolil()
+    adj[adj > 1] = 1
+    if require_lcc:
+        _, comp = sp.csgraph.connected_components(adj)
+        keep_comp = np.argsort(np.bincount(comp))[::-1][0]
+        keep = np.flatnonzero(comp == keep_comp)
+        adj = adj[keep][:, keep]
+        feats = feats[keep]
+        labels = labels[keep] if labels is not None else None
+        if np.asarray(adj.sum(0)).ravel().min() <= 0:
+            raise ValueError("graph contains singleton nodes")
+    adj.setdiag(0)
+    adj = adj.astype(np.float32).tocsr()
+    adj.eliminate_zeros()
+    if abs(adj - adj.T).sum() != 0:
+        raise ValueError("input graph is not symmetric")
+    if adj.nnz and not (adj.max() == 1 and np.all(adj.data == 1)):
+        raise ValueError("graph must be unweighted")
+    return adj, feats, labels

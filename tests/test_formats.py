@@ -71,3 +71,30 @@ def test_host_timers_accumulate():
     assert t.c.af.n_calls == 3 and t.c.af.ms() == 0.0     # no device here: the device leg is off
     t.reset()
     assert t.h.af.n_calls == 0
+
+
+def test_deeprobust_npz_file(tmp_path):
+    """the .npz dataset layout of dataio.py:128-150 and its post-processing (:106-126): symmetrise,
+    binarise, largest connected component, zero diagonal"""
+    rng = np.random.default_rng(1)
+    n = 60
+    # component A: vertices 0..39 (ring + chords, some entries doubled and directed), component B: 40..54 (ring),
+    # 55..59 isolated
+    r = list(range(40)) + [3, 7, 7] + list(range(40, 55))
+    c = [(i + 1) % 40 for i in range(40)] + [20, 30, 30] + [40 + (i + 1) % 15 for i in range(15)]
+    A = sp.coo_matrix((np.ones(len(r)), (r, c)), shape=(n, n)).tocsr()       # directed, (7,30) stored twice -> 2.0
+    A[5, 5] = 1.0                                                            # a self-loop to be dropped
+    X = sp.random(n, 9, density=0.3, random_state=3, format="csr")
+    y = rng.integers(0, 4, n)
+    path = tmp_path / "toy.npz"
+    np.savez(path, adj_data=A.data, adj_indices=A.indices, adj_indptr=A.indptr, adj_shape=A.shape,
+             attr_data=X.data, attr_indices=X.indices, attr_indptr=X.indptr, attr_shape=X.shape, labels=y)
+    adj, feats, labels = gio.load_deeprobust_npz(str(path))
+    assert adj.shape == (40, 40) and feats.shape == (40, 9) and labels.shape == (40,)
+    assert adj.dtype == np.float32 and abs(adj - adj.T).sum() == 0 and adj.diagonal().sum() == 0
+    assert set(np.unique(adj.data)) == {1.0} and adj.nnz == 2 * (40 + 2)     # ring + two distinct chords
+    assert np.array_equal(labels, y[:40]) and np.allclose(feats.toarray(), X[:40].toarray())
+    # without the component filter: all vertices stay, no features -> identity
+    np.savez(tmp_path / "nofeat.npz", adj_data=A.data, adj_indices=A.indices, adj_indptr=A.indptr, adj_shape=A.shape)
+    adj2, feats2, labels2 = gio.load_deeprobust_npz(str(tmp_path / "nofeat.npz"), require_lcc=False)
+    assert adj2.shape == (n, n) and labels2 is None and (feats2 != sp.identity(n)).nnz == 0
