@@ -23,7 +23,18 @@ SHAPES = {
     "cora":     dict(n=2485, edges=5069, abcd=(0.25, 0.25, 0.25, 0.25)),
     "reddit":   dict(n=232965, edges=57307946, abcd=(0.37, 0.25, 0.25, 0.13)),
     "products": dict(n=2449029, edges=61859140, abcd=(0.45, 0.22, 0.22, 0.11)),
+    # the other graphs of the reference's run.sh sweep (GraphSAINT datasets; vertex / undirected-edge /
+    # feature / class counts as published by Zeng et al., "GraphSAINT", ICLR 2020, Table 2, and for
+    # pubmed by Planetoid) — shapes only, for tools/run_sweep.sh; none of them is a BASELINE config
+    "pubmed":   dict(n=19717, edges=44324, abcd=(0.45, 0.22, 0.22, 0.11), nfeat=500, nclass=3),
+    "flickr":   dict(n=89250, edges=899756, abcd=(0.45, 0.22, 0.22, 0.11), nfeat=500, nclass=7),
+    "ppi":      dict(n=14755, edges=225270, abcd=(0.45, 0.22, 0.22, 0.11), nfeat=50, nclass=121),
+    "yelp":     dict(n=716847, edges=6977410, abcd=(0.45, 0.22, 0.22, 0.11), nfeat=300, nclass=100),
+    "amazon":   dict(n=1598960, edges=132169734, abcd=(0.45, 0.22, 0.22, 0.11), nfeat=200, nclass=107),
 }
+SHAPES["reddit"].update(nfeat=602, nclass=41)
+SHAPES["products"].update(nfeat=100, nclass=47)
+SHAPES["cora"].update(nfeat=1433, nclass=7)
 
 
 def _rmat_pairs(n, count, abcd, gen, device):

@@ -32,8 +32,8 @@ def main():
                     help="layer 2 as the reference hard-codes it per dataset, or with the SpMM at the narrower width")
     ap.add_argument("--warmup-iters", type=int, default=3, help="untimed iterations before the timed ones (0: as the reference)")
     ap.add_argument("--scale", type=float, default=1.0)
-    ap.add_argument("--nfeat", type=int, default=602)       # Reddit's input width
-    ap.add_argument("--nclass", type=int, default=41)
+    ap.add_argument("--nfeat", type=int, default=0, help="input width of the synthetic stand-in (0: the dataset's published one)")
+    ap.add_argument("--nclass", type=int, default=0, help="classes of the synthetic stand-in (0: the dataset's published count)")
     args = ap.parse_args()
     seed = 15                                               # profiling_gcn.py:76-80
     np.random.seed(seed); torch.manual_seed(seed); torch.cuda.manual_seed(seed)
@@ -45,6 +45,8 @@ def main():
         normalize = True
     else:
         shape = args.graph if args.graph in graphgen.SHAPES else "reddit"
+        args.nfeat = args.nfeat or graphgen.SHAPES[shape].get("nfeat", 602)
+        args.nclass = args.nclass or graphgen.SHAPES[shape].get("nclass", 41)
         rp, ci, va, n = graphgen.make_graph(shape, device="cuda:0", seed=1, scale=args.scale)
         adj = sp.csr_matrix((va.cpu().numpy(), ci.cpu().numpy(), rp.cpu().numpy()), shape=(n, n))
         normalize = False                                   # the generator already returns Â
