@@ -155,11 +155,12 @@ class GCN(nn.Module):
         adj_norm = preprocess.normalize_adj_tensor(adj) if normalize else preprocess.sparse_mx_to_torch_sparse_tensor(adj)
         rp, ci, va, vo_mp = preprocess.to_csr_int32(adj_norm)
         dev = torch.device(self.device)
-        if self.order in ("rcm", "deg"):                                         # step 1 on the GPU
+        if self.order in ("rcm", "deg", "communities"):                          # step 1 on the GPU
             # the reference library's internal orderings (order_rcm.cu, order_deg.cu), computed by the
             # device kernels — same integers as the host code, ~100x faster (reorder_device.hip)
             rp, ci, va = rp.to(dev), ci.to(dev), va.to(dev)
             rank = (reorder.order_rcm_device(rp, ci) if self.order == "rcm"
+                    else reorder.order_communities_device(rp, ci) if self.order == "communities"
                     else reorder.order_deg_device(rp, ci, "total", True))
             rp, ci, va, vo_mp = reorder.apply_rank_device(rp, ci, va, rank)
         else:

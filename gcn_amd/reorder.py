@@ -157,3 +157,88 @@ def apply_rank_device(rowptr, col, vals, rank):
                                                      p(vomp), ctypes.c_void_p(torch.cuda.current_stream(d).cuda_stream)),
                "gcn_csr_apply_rank_device")
     return o_rp, o_ci, o_va, vomp
+
+
+def order_communities_device(rowptr, col, max_rounds=24, min_merge_frac=0.002, return_levels=False):
+    """A GPU community ordering in the spirit of Rabbit (incremental modularity aggregation,
+    renumber.cu:319-522 / Arai et al. 2016) — SURVEY §8f.4's "parallel Rabbit", opt-in: it is NOT the
+    reference's serial merge order and does not reproduce its integers (use `rabbit` for those).
+
+    Rounds of parallel aggregation on the device: every community u picks the neighbouring community v
+    with the largest modularity gain  w_uv − deg_u·deg_v / 2m  (> 0, ties to the smaller id) and merges
+    into it when (deg_u, u) < (deg_v, v) — smaller into larger — and v is not itself merging this round
+    (stars, no chains); the graph is contracted (sort + reduce by key) and the round repeats.  The final order keeps every community of every round contiguous (a stable sort per round,
+    last round most significant) — the leaf order of the merge dendrogram.
+    → rank[old]=new (int64, on the input device)."""
+    import torch
+    dev = rowptr.device
+    n = rowptr.numel() - 1
+    rows = torch.repeat_interleave(torch.arange(n, device=dev, dtype=torch.int64), (rowptr[1:] - rowptr[:-1]).long())
+    cols = col.long()
+    keep = rows != cols
+    u, v = rows[keep], cols[keep]
+    del rows, cols, keep
+    # symmetrise the pattern, unit weights, no duplicates
+    key = torch.unique(torch.cat([u * n + v, v * n + u]))
+    u, v = key // n, key % n
+    w = torch.ones_like(u, dtype=torch.float64)
+    del key
+    deg = torch.bincount(u, minlength=n).double()               # community degree (sum over members)
+    two_m = float(deg.sum())
+    if two_m == 0:
+        r = torch.arange(n, device=dev, dtype=torch.int64)
+        return (r, 0) if return_levels else r
+    comm = torch.arange(n, device=dev, dtype=torch.int64)       # community of every ORIGINAL vertex
+    levels = []
+    ncomm = n
+    for _round in range(max_rounds):
+        if u.numel() == 0:
+            break
+        gain = w - deg[u] * deg[v] / two_m
+        # allowed direction: smaller (degree, id) into larger
+        ok = (gain > 0) & ((deg[u] < deg[v]) | ((deg[u] == deg[v]) & (u < v)))
+        if not bool(ok.any()):
+            break
+        gu, gv, gg = u[ok], v[ok], gain[ok]
+        # per u: the largest gain, ties to the smaller v  (sort by (u, -gain, v), take the first of each u)
+        order = torch.argsort(gv, stable=True)
+        gu, gv, gg = gu[order], gv[order], gg[order]
+        order = torch.argsort(-gg, stable=True)
+        gu, gv, gg = gu[order], gv[order], gg[order]
+        order = torch.argsort(gu, stable=True)
+        gu, gv = gu[order], gv[order]
+        first = torch.ones_like(gu, dtype=torch.bool)
+        first[1:] = gu[1:] != gu[:-1]
+        ident = torch.arange(ncomm, device=dev, dtype=torch.int64)
+        parent = ident.clone()
+        parent[gu[first]] = gv[first]
+        # stars only: a community that is itself merging this round takes no members (its would-be members
+        # wait for the next round, when the weights to the merged community are known) — chains of
+        # merges would otherwise sweep across community borders in a single round
+        moving = parent != ident
+        parent = torch.where(moving & moving[parent], ident, parent)
+        merged = int((parent != ident).sum())
+        if merged == 0:
+            break
+        # compact the surviving roots to 0..ncomm'-1
+        roots, newid = torch.unique(parent, return_inverse=True)
+        comm = newid[comm]
+        levels.append(comm.clone())
+        deg = torch.zeros(roots.numel(), device=dev, dtype=torch.float64).index_add_(0, newid, deg)
+        ncomm = int(roots.numel())
+        # contract the edge list
+        u, v = newid[u], newid[v]
+        keep = u != v
+        key = u[keep] * ncomm + v[keep]
+        wk = w[keep]
+        key, inv = torch.unique(key, return_inverse=True)
+        w = torch.zeros(key.numel(), device=dev, dtype=torch.float64).index_add_(0, inv, wk)
+        u, v = key // ncomm, key % ncomm
+        if merged < min_merge_frac * n:
+            break
+    order = torch.arange(n, device=dev, dtype=torch.int64)
+    for lab in levels:                                          # least significant (first round) first
+        order = order[torch.argsort(lab[order], stable=True)]
+    rank = torch.empty(n, device=dev, dtype=torch.int64)
+    rank[order] = torch.arange(n, device=dev, dtype=torch.int64)
+    return (rank, len(levels)) if return_levels else rank

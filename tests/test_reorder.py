@@ -151,3 +151,29 @@ def test_order_deg_device_variant_equals_host():
         for desc in (True, False):
             got = reorder.order_deg_device(torch.from_numpy(rp), torch.from_numpy(ci2), which, desc).numpy()
             assert np.array_equal(got, reorder.order_deg(rp, ci2, which, desc)), (which, desc)
+
+
+def test_gpu_style_community_ordering_is_a_permutation_that_groups_planted_communities():
+    """order_communities_device (opt-in, NOT the reference's integers): pure tensor code, so its logic
+    is checked here on the CPU: a valid, deterministic permutation under which most neighbours in the
+    new order come from the same planted community, and which rewrites the CSR consistently"""
+    import torch
+    from gcn_amd import graphgen
+    n = 6000
+    rowptr, col, val, _ = graphgen.make_sbm(n, device="cpu", seed=7)
+    rank, levels = reorder.order_communities_device(rowptr, col, return_levels=True)
+    assert levels >= 3 and sorted(rank.tolist()) == list(range(n))
+    assert torch.equal(rank, reorder.order_communities_device(rowptr, col))
+    gen = torch.Generator(); gen.manual_seed(7 + 1000)
+    perm = torch.randperm(n, generator=gen)                                  # make_sbm's relabelling
+    block = torch.empty(n, dtype=torch.long); block[perm] = torch.arange(n) // 512
+    order = torch.argsort(rank)
+    same = float((block[order][1:] == block[order][:-1]).float().mean())
+    assert same > 0.7, same                                                  # random order: ~0.08
+    rp2, ci2, va2, vomp = reorder.apply_rank(rowptr.numpy(), col.numpy(), val.numpy(), rank.numpy())
+    A = sp.csr_matrix((val.numpy(), col.numpy(), rowptr.numpy()), shape=(n, n))
+    B = sp.csr_matrix((va2, ci2, rp2), shape=(n, n))
+    assert abs(B - A[vomp][:, vomp]).max() == 0
+    # degenerate inputs
+    e = torch.zeros(5, dtype=torch.int32)
+    assert reorder.order_communities_device(torch.zeros(5, dtype=torch.int32), e[:0]).tolist() == [0, 1, 2, 3]

@@ -26,7 +26,7 @@ def main():
     ap.add_argument("-g", "--graph", default="reddit")
     ap.add_argument("-k", "--hidden", type=int, default=128)
     ap.add_argument("-i", "--train-iters", dest="train_iters", type=int, default=100)
-    ap.add_argument("--order", default="none", choices=["none", "dfs", "gorder", "rabbit", "rcm", "deg"])
+    ap.add_argument("--order", default="none", choices=["none", "dfs", "gorder", "rabbit", "rcm", "deg", "communities"])
     ap.add_argument("--fuse", action="store_true", help="bias + ReLU in the SpMM epilogue")
     ap.add_argument("--layer-order", default="reference", choices=["reference", "auto"],
                     help="layer 2 as the reference hard-codes it per dataset, or with the SpMM at the narrower width")

@@ -74,6 +74,12 @@ def main():
             rp2, ci2, va2, vomp = reorder.dfs(rp, ci, va)
         elif name == "rabbit":
             rp2, ci2, va2, vomp = reorder.rabbit(rp, ci, va)
+        elif name in ("comm_gpu", "rcm_gpu"):                    # device orderings + device CSR rewrite
+            rank = (reorder.order_communities_device(rowptr, col) if name == "comm_gpu"
+                    else reorder.order_rcm_device(rowptr, col))
+            out_d = reorder.apply_rank_device(rowptr, col, val, rank)
+            torch.cuda.synchronize()
+            rp2, ci2, va2, vomp = [x.cpu().numpy() for x in out_d]
         else:
             raise SystemExit(f"unknown order {name}")
         t_re = time.time() - t0
