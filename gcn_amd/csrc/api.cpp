@@ -38,6 +38,7 @@ struct gcn_spmm_plan {
   int* vchunk_row;              // [nchunks] rows of the virtual CSR
   float* cv;                    // partial outputs [S*m x k], grow-only
   size_t cv_bytes;
+  float* u;                     // [n] factor of rank-1 values (val[r,c] = u[r]*u[c]), null when they are not
   float* bpad;                  // B re-laid with rows padded to whole 128-byte lines (odd k), grow-only
   size_t bpad_bytes;
   float* cpad;                  // result with k rounded up to a multiple of 4 (k % 4 != 0), grow-only
@@ -99,6 +100,12 @@ int auto_tile_cols(long long n, int k) {
   if (n * 256 <= budget) return 64;
   if (n * 512 <= budget && k > 128) return 128;
   return 0;                                      // widest tile k allows (<= 256 columns)
+}
+
+// value-free sliced main pass for matrices whose values factor as u[r]*u[c] (development knob GCN_AMD_VALLESS=0: off)
+static bool valless_enabled() {
+  static const bool v = [] { const char* e = std::getenv("GCN_AMD_VALLESS"); return !e || e[0] != '0'; }();
+  return v;
 }
 
 // re-lay B with rows padded to whole cache lines for k % 32 != 0 (development knob GCN_AMD_PAD_B=0: off)
@@ -234,6 +241,7 @@ int gcn_spmm_plan_create(gcn_spmm_plan_t** out, const int32_t* rowptr_dev, int32
   p->chunk_row = nullptr; p->ws = nullptr; p->ws_bytes = 0; p->cu_count = cu;
   p->prof_cap = p->prof_n = 0;
   p->tile_cols = 0;
+  p->u = nullptr;
   p->bpad = nullptr; p->bpad_bytes = 0;
   p->cpad = nullptr; p->cpad_bytes = 0;
   p->blocks_per_cu = 32;
@@ -261,6 +269,7 @@ int gcn_spmm_plan_destroy(gcn_spmm_plan_t* p) {
   if (p->vval) (void)hipFree(p->vval);
   if (p->vchunk_row) (void)hipFree(p->vchunk_row);
   if (p->cv) (void)hipFree(p->cv);
+  if (p->u) (void)hipFree(p->u);
   if (p->bpad) (void)hipFree(p->bpad);
   if (p->cpad) (void)hipFree(p->cpad);
   {
@@ -337,23 +346,36 @@ static int spmm_impl(gcn_spmm_plan_t* p, const int32_t* rowptr, const int32_t* c
   a.chunk_row = p->chunk_row; a.bias = bias; a.relu = relu ? 1 : 0;
   a.nchunks = p->nchunks; a.T = p->T; a.m = p->m; a.nnz = p->nnz; a.k = k; a.n = p->n;
   a.nnz_dev = nullptr; a.nchunks_grid = p->nchunks;
-  // Feature rows that are not a whole number of 128-byte cache lines straddle lines: a gathered row
-  // then costs up to one extra L2 request per tile.  Where that matters (padded_ldb) B is first re-laid
-  // with its rows padded to the next multiple of 32 floats (one streaming copy, ~45 us for 233 k x 100)
-  // and gathered from there; C keeps the caller's layout.
-  if (b_ld > 0) {
-    a.ldb = b_ld;                                      // already re-laid by the caller (odd-width path)
-  } else if (const int ldb = padded_ldb(p->n, k); p->nnz > 0 && ldb != k) {
-    const int st = grow(p->bpad, p->bpad_bytes, sizeof(float) * (size_t)p->n * (size_t)ldb);
-    if (st != GCN_OK) return st;
-    if (gcn::launch_pad_rows(p->bpad, B, p->n, k, ldb, (hipStream_t)stream) != hipSuccess) return GCN_ERR_HIP;
-    a.B = p->bpad;
-    a.ldb = ldb;
-  }
   // narrow feature widths (k <= 32, the GCN hidden/class sizes) gather 128 B or less per
   // non-zero: there the extra partial rows cost more than the L2 hits buy (measured 2.12 vs
   // 2.02 ms at k = 32), so the sliced copy is used for k > 32 only
   const bool sliced = p->S > 0 && p->nnz > 0 && k >= slice_min_k();
+  // Feature rows that are not a whole number of 128-byte cache lines straddle lines: a gathered row
+  // then costs up to one extra L2 request per tile.  Where that matters (padded_ldb) B is first re-laid
+  // with its rows padded to the next multiple of 32 floats (one streaming copy, ~45 us for 233 k x 100)
+  // and gathered from there; C keeps the caller's layout.  The same copy carries the row scaling of the
+  // value-free pass (values u[r]*u[c], sliced matrix, four-per-gather kernel): B' = diag(u) B.
+  bool valless = false;
+  if (b_ld > 0) {
+    a.ldb = b_ld;                                      // already re-laid by the caller (odd-width path)
+  } else if (p->nnz > 0) {
+    const int ldb = padded_ldb(p->n, k);
+    if (sliced && p->u && p->panel_R == 0) {
+      gcn::SpmmArgs t = a;                             // the launch as the sliced branch below will issue it
+      t.B = nullptr; t.C = nullptr; t.bias = nullptr; t.relu = 0;
+      t.m = p->S * p->m; t.ldb = ldb; t.tile_cols = p->tile_cols ? p->tile_cols : 64;
+      t.gather_width = p->gather_width;
+      valless = gcn::spmm_will_use_quad(t) && gcn::spmm_quad_lanes(k) == 16;
+    }
+    if (ldb != k || valless) {
+      const int st = grow(p->bpad, p->bpad_bytes, sizeof(float) * (size_t)p->n * (size_t)ldb);
+      if (st != GCN_OK) return st;
+      if (gcn::launch_pad_rows(p->bpad, B, p->n, k, ldb, (hipStream_t)stream, valless ? p->u : nullptr) != hipSuccess)
+        return GCN_ERR_HIP;
+      a.B = p->bpad;
+      a.ldb = ldb;
+    }
+  }
   if (p->panel_R > 0 && p->nnz > 0 && k > 32) {
     // A = A_in + A_out: the staged part from LDS (raw sums into C), then the rest accumulated by the
     // chunk kernel, which also carries the epilogue
@@ -418,9 +440,11 @@ static int spmm_impl(gcn_spmm_plan_t* p, const int32_t* rowptr, const int32_t* c
     }
     a.rowptr = p->vrowptr; a.col = p->vcol; a.val = p->vval; a.chunk_row = p->vchunk_row;
     a.C = p->cv; a.m = p->S * p->m; a.bias = nullptr; a.relu = 0;
+    const float* rowscale = nullptr;
+    if (valless) { a.valless = 1; a.val = nullptr; rowscale = p->u; }   // B was scaled by u above
     if (gcn::launch_spmm(a, p->cu_count, (hipStream_t)stream) != hipSuccess) return GCN_ERR_HIP;
     return gcn::launch_slice_reduce(p->cv, C, bias, relu ? 1 : 0, p->m, p->S, k,
-                                    (hipStream_t)stream) == hipSuccess ? GCN_OK : GCN_ERR_HIP;
+                                    (hipStream_t)stream, 0, rowscale) == hipSuccess ? GCN_OK : GCN_ERR_HIP;
   }
   return gcn::launch_spmm(a, p->cu_count, (hipStream_t)stream) == hipSuccess ? GCN_OK : GCN_ERR_HIP;
 }
@@ -431,6 +455,8 @@ static void free_slicing(gcn_spmm_plan* p) {
   if (p->vval) (void)hipFree(p->vval);
   if (p->vchunk_row) (void)hipFree(p->vchunk_row);
   if (p->cv) (void)hipFree(p->cv);
+  if (p->u) (void)hipFree(p->u);
+  p->u = nullptr;
   p->vrowptr = p->vcol = p->vchunk_row = nullptr; p->vval = nullptr; p->cv = nullptr;
   p->cv_bytes = 0; p->S = 0;
 }
@@ -468,6 +494,17 @@ int gcn_spmm_plan_enable_slicing(gcn_spmm_plan_t* p, const int32_t* rowptr, cons
     return GCN_ERR_HIP;
   }
   p->S = slices;
+  // Normalised adjacencies (D^-1/2 (A+I) D^-1/2) have values u[r]*u[c]: when every stored entry matches
+  // that to 4 ulp the sliced main pass can run without its value stream (spmm_quad.hip, VALLESS) on a
+  // B whose rows were scaled by u, with the row factor applied in the slice reduction.
+  if (p->m == p->n && valless_enabled()) {
+    if (hipMalloc((void**)&p->u, sizeof(float) * (size_t)p->n) != hipSuccess) { p->u = nullptr; return GCN_OK; }
+    int ok = 0;
+    if (gcn::detect_rank1_values(rowptr, col, val, p->n, p->u, &ok, (hipStream_t)stream) != hipSuccess || !ok) {
+      (void)hipFree(p->u);
+      p->u = nullptr;
+    }
+  }
   return GCN_OK;
 }
 
@@ -601,7 +638,10 @@ int gcn_spmm_plan_main_kernel(const gcn_spmm_plan_t* p, int32_t k, int32_t epilo
     a.k = (k + 3) / 4 * 4;                             // odd widths run at k rounded up to 4 (see gcn_spmm_csr_f32_bias_relu)
     a.ldb = (a.k + 31) / 32 * 32;
     a.relu = 0;
-  } else if (const int ldb = padded_ldb(p->n, k); ldb != k) a.ldb = ldb;
+  } else {
+    if (const int ldb = padded_ldb(p->n, k); ldb != k) a.ldb = ldb;
+    if (sliced && p->u) a.valless = gcn::spmm_will_use_quad(a) && gcn::spmm_quad_lanes(k) == 16;   // as spmm_impl decides
+  }
   gcn::describe_main_kernel(a, buf, (size_t)buflen);
   return GCN_OK;
 }

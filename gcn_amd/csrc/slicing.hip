@@ -85,20 +85,17 @@ slice_scatter_kernel(const int* __restrict__ rowptr, const int* __restrict__ col
 template <int VEC>
 __global__ void __launch_bounds__(256)
 slice_reduce_kernel(const float* __restrict__ Cv, float* __restrict__ C,
-                    const float* __restrict__ bias, int relu, int m, int S, int k, int accumulate) {
+                    const float* __restrict__ bias, int relu, int m, int S, int k, int accumulate,
+                    const float* __restrict__ rowscale) {
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int nw = gridDim.x * 4;
   for (int r = wave; r < m; r += nw) {
+    const float rs = rowscale ? rowscale[r] : 1.f;    // value-free main pass: the row's own factor u[r]
     for (int x = lane * VEC; x < k; x += 64 * VEC) {
       float acc[VEC];
 #pragma unroll
       for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
-      if (accumulate) {                             // C already holds another part of the product
-        const float* o = C + (size_t)r * (size_t)k + x;
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) acc[i] = o[i];
-      }
       for (int s = 0; s < S; ++s) {
         const float* p = Cv + ((size_t)s * m + r) * (size_t)k + x;
         if (VEC == 4) {
@@ -108,6 +105,15 @@ slice_reduce_kernel(const float* __restrict__ Cv, float* __restrict__ C,
 #pragma unroll
           for (int i = 0; i < VEC; ++i) acc[i] += p[i];
         }
+      }
+      if (rowscale) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i] *= rs;
+      }
+      if (accumulate) {                             // C already holds another part of the product
+        const float* o = C + (size_t)r * (size_t)k + x;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i] += o[i];
       }
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
@@ -179,14 +185,68 @@ hipError_t build_sliced_csr(const int* rowptr, const int* col, const float* val,
 }
 
 hipError_t launch_slice_reduce(const float* Cv, float* C, const float* bias, int relu, int m, int S,
-                               int k, hipStream_t st, int accumulate) {
+                               int k, hipStream_t st, int accumulate, const float* rowscale) {
   if (m <= 0 || k <= 0) return hipSuccess;
   int nb = (m + 3) / 4;
   if (nb > 8192) nb = 8192;
   const uintptr_t al = (uintptr_t)Cv | (uintptr_t)C | (uintptr_t)bias;
-  if (k % 4 == 0 && (al & 15) == 0) slice_reduce_kernel<4><<<nb, 256, 0, st>>>(Cv, C, bias, relu, m, S, k, accumulate);
-  else                              slice_reduce_kernel<1><<<nb, 256, 0, st>>>(Cv, C, bias, relu, m, S, k, accumulate);
+  if (k % 4 == 0 && (al & 15) == 0) slice_reduce_kernel<4><<<nb, 256, 0, st>>>(Cv, C, bias, relu, m, S, k, accumulate, rowscale);
+  else                              slice_reduce_kernel<1><<<nb, 256, 0, st>>>(Cv, C, bias, relu, m, S, k, accumulate, rowscale);
   return hipGetLastError();
+}
+
+// ---- do the values factor as u[r] * u[c]?  (the GCN normalisation D^-1/2 (A+I) D^-1/2: u = D^-1/2) ----
+// u[r] = sqrt(A[r, r]) from the stored diagonal (binary search in the column-sorted row)
+__global__ void rank1_diag_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
+                                  const float* __restrict__ val, int n, float* __restrict__ u, int* __restrict__ fail) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  int lo = rowptr[r], hi = rowptr[r + 1];
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (col[mid] < r) lo = mid + 1; else hi = mid;
+  }
+  if (lo < rowptr[r + 1] && col[lo] == r && val[lo] > 0.f) u[r] = (float)sqrt((double)val[lo]);
+  else { u[r] = 0.f; *fail = 1; }
+}
+
+// every stored entry within 4 ulp of u[r] * u[c]; one wave per row
+__global__ void __launch_bounds__(256)
+rank1_check_kernel(const int* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ val,
+                   const float* __restrict__ u, int n, int* __restrict__ fail) {
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int nw = gridDim.x * 4;
+  for (int r = wave; r < n; r += nw) {
+    const float ur = u[r];
+    for (int e = rowptr[r] + lane; e < rowptr[r + 1]; e += 64) {
+      const float want = ur * u[col[e]];
+      if (!(fabsf(val[e] - want) <= 4.8e-7f * fabsf(val[e]))) *fail = 1;
+    }
+  }
+}
+
+hipError_t detect_rank1_values(const int* rowptr, const int* col, const float* val, int n, float* u_out,
+                               int* ok_host, hipStream_t st) {
+  *ok_host = 0;
+  if (n <= 0) return hipSuccess;
+  int* fail = nullptr;
+  hipError_t e = hipMalloc((void**)&fail, sizeof(int));
+  if (e != hipSuccess) return e;
+  int h = 1;
+  e = hipMemsetAsync(fail, 0, sizeof(int), st);
+  if (e == hipSuccess) {
+    rank1_diag_kernel<<<(n + 255) / 256, 256, 0, st>>>(rowptr, col, val, n, u_out, fail);
+    int nb = (n + 3) / 4;
+    if (nb > 16384) nb = 16384;
+    rank1_check_kernel<<<nb, 256, 0, st>>>(rowptr, col, val, u_out, n, fail);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(&h, fail, sizeof(int), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  (void)hipFree(fail);
+  if (e == hipSuccess) *ok_host = h ? 0 : 1;
+  return e;
 }
 
 }  // namespace gcn

@@ -29,6 +29,7 @@ struct SpmmArgs {
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
   int tile_cols = 0;       // feature-column tile per pass: 0 auto, else 64 / 128 / 256
   int accumulate = 0;      // 1: C += A*B (C already holds another part of the product); epilogue after the add
+  int valless = 0;         // 1: ignore val (every entry counts 1): the caller pre-scaled B and post-scales the rows
   int gather_width = 0;    // 64-column tile: non-zeros per gather instruction, 0 auto (4 when eligible), 1, 4
   int blocks_per_cu = 32;  // grid size in 256-thread blocks per CU (1..64).  Up to 8 (4 for the 108-VGPR
                            // quad kernel) are resident; more = later blocks start as earlier ones end, i.e.
@@ -43,7 +44,10 @@ hipError_t launch_spmm(const SpmmArgs& a, int cu_count, hipStream_t s);
 hipError_t launch_gather_rows(float* dst, const float* src, const int* idx, int nrows, int k,
                               hipStream_t s);
 // dst[r, 0:k] = src[r, 0:k], dst[r, k:ld] = 0 for r < rows (dst row stride ld >= k)
-hipError_t launch_pad_rows(float* dst, const float* src, long long rows, int k, int ld, hipStream_t s);
+hipError_t launch_pad_rows(float* dst, const float* src, long long rows, int k, int ld, hipStream_t s,
+                           const float* rowscale = nullptr);   // dst[r, :] = rowscale[r] * src[r, :] when given
+// true when launch_spmm will run the four-per-gather kernel for these arguments
+bool spmm_will_use_quad(const SpmmArgs& a);
 // dst[r, 0:k] = act(src[r, 0:k] + bias), src row stride ld >= k
 hipError_t launch_unpad_rows(float* dst, const float* src, const float* bias, int relu, long long rows, int k,
                              int ld, hipStream_t s);
@@ -83,6 +87,9 @@ hipError_t build_sliced_csr(const int* rowptr, const int* col, const float* val,
                             int nnz, int S, int* vrowptr, int* vcol, float* vval,
                             int* sorted_out, hipStream_t st);
 hipError_t launch_slice_reduce(const float* Cv, float* C, const float* bias, int relu, int m, int S,
-                               int k, hipStream_t st, int accumulate = 0);
+                               int k, hipStream_t st, int accumulate = 0, const float* rowscale = nullptr);
+// values factor as u[r]*u[c]?  u_out[n] (device), *ok_host = 1 when every stored entry matches within 4 ulp
+hipError_t detect_rank1_values(const int* rowptr, const int* col, const float* val, int n, float* u_out,
+                               int* ok_host, hipStream_t st);
 
 }  // namespace gcn

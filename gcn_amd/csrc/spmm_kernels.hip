@@ -406,6 +406,8 @@ static bool use_quad(const SpmmArgs& a) {
   return a.k <= 32 || pick_vec(a.k, a.tile_cols, a.B, a.C, a.P) == 1;
 }
 
+bool spmm_will_use_quad(const SpmmArgs& a) { return a.nchunks_grid > 0 && use_quad(a); }
+
 hipError_t launch_spmm(const SpmmArgs& a, int cu_count, hipStream_t s) {
   const bool epi = (a.bias != nullptr) || a.relu;
   if (a.m <= 0 || a.k <= 0) return hipSuccess;
@@ -426,6 +428,7 @@ hipError_t launch_spmm(const SpmmArgs& a, int cu_count, hipStream_t s) {
   hipError_t e;
   if (a.ev_start && (e = hipEventRecord(a.ev_start, s)) != hipSuccess) return e;
   static const bool narrow_on = [] { const char* v = getenv("GCN_AMD_NARROW"); return !v || v[0] != '0'; }();
+  if (a.valless && !use_quad(a)) return hipErrorInvalidValue;
   if (use_quad(a)) {
     // 16-byte-per-lane gathers, 4 (k > 16) or 16 (k <= 16) non-zeros per instruction (spmm_quad.hip)
     e = launch_spmm_quad(a, nblocks, epi, s);
@@ -469,7 +472,10 @@ void describe_main_kernel(const SpmmArgs& a, char* buf, size_t len) {
   static const int u1 = [] { const char* v = getenv("GCN_AMD_U1"); return v ? atoi(v) : 32; }();
   const bool buf32 = (unsigned long long)a.n * (unsigned long long)(a.ldb > 0 ? a.ldb : a.k) * 4ull < 0xFFFFFFF0ull;
   if (a.nchunks_grid == 0) { snprintf(buf, len, "gcn::spmm_empty_kernel"); return; }
-  if (use_quad(a)) { snprintf(buf, len, "gcn::spmm_quad_kernel<%d, %s>", spmm_quad_lanes(a.k), e); return; }
+  if (use_quad(a)) {
+    snprintf(buf, len, "gcn::spmm_quad_kernel<%d, %s, %s>", spmm_quad_lanes(a.k), e, a.valless ? "true" : "false");
+    return;
+  }
   if (a.k <= 16 && narrow_on && (a.ldb == 0 || a.ldb == a.k)) {
     if (a.k > 8 && buf32 && a.n < (1 << 24)) snprintf(buf, len, "gcn::spmm_narrow16_dpp_kernel<%s>", e);
     else {
@@ -487,21 +493,23 @@ void describe_main_kernel(const SpmmArgs& a, char* buf, size_t len) {
 
 // dst[r, 0:k] = src[r, 0:k], dst[r, k:ld] = 0: feature rows re-laid on whole 128-byte lines
 __global__ void __launch_bounds__(256)
-pad_rows_kernel(float* __restrict__ dst, const float* __restrict__ src, long long rows, int k, int ld) {
+pad_rows_kernel(float* __restrict__ dst, const float* __restrict__ src, long long rows, int k, int ld,
+                const float* __restrict__ rowscale) {
   const long long total = rows * ld;
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
     const long long r = i / ld;
     const int c = (int)(i - r * ld);
-    dst[i] = c < k ? src[r * k + c] : 0.f;
+    dst[i] = c < k ? (rowscale ? rowscale[r] * src[r * k + c] : src[r * k + c]) : 0.f;
   }
 }
 
-hipError_t launch_pad_rows(float* dst, const float* src, long long rows, int k, int ld, hipStream_t s) {
+hipError_t launch_pad_rows(float* dst, const float* src, long long rows, int k, int ld, hipStream_t s,
+                           const float* rowscale) {
   if (rows <= 0 || k <= 0) return hipSuccess;
   long long nb = (rows * ld + 255) / 256;
   if (nb > 65536) nb = 65536;
-  pad_rows_kernel<<<(int)nb, 256, 0, s>>>(dst, src, rows, k, ld);
+  pad_rows_kernel<<<(int)nb, 256, 0, s>>>(dst, src, rows, k, ld, rowscale);
   return hipGetLastError();
 }
 

@@ -64,7 +64,11 @@ __device__ __forceinline__ float4 quad_reduce(float4 t) {
 // 64/LPE non-zeros.  (An 8-lane / 32-column layout was measured for k = 17..32 and bought nothing over
 // the 16-lane layout with half its lanes idle — 1.61 vs 1.59 ms on the Reddit-shaped graph: narrow
 // widths are bound by L2 requests per non-zero, not by instructions — so it is not instantiated.)
-template <int LPE, bool EPI>
+// VALLESS: the matrix values are not read at all — every stored entry counts 1.  For adjacencies whose
+// values factor as u[r]*u[c] (the GCN normalisation D^-1/2 (A+I) D^-1/2) the caller pre-scales B's rows by
+// u and scales the finished rows by u[r] (api.cpp, slice_reduce_kernel): the 4-byte value stream is
+// 5 % of what the sliced kernel moves across the fabric, and fabric bytes are its time.
+template <int LPE, bool EPI, bool VALLESS>
 __global__ void __launch_bounds__(256)
 spmm_quad_kernel(const int* __restrict__ g_rowptr, const int* __restrict__ g_col,
                  const float* __restrict__ g_val, const float* __restrict__ g_B,
@@ -151,20 +155,20 @@ spmm_quad_kernel(const int* __restrict__ g_rowptr, const int* __restrict__ g_col
 
     int   cj_nx = 0;
     float vj_nx = 0.f;
-    if (start + tl < end) { cj_nx = a.col[start + tl]; vj_nx = a.val[start + tl]; }
+    if (start + tl < end) { cj_nx = a.col[start + tl]; if (!VALLESS) vj_nx = a.val[start + tl]; }
     for (int base = start; base < end; base += 64) {
       const int cnt = min(64, end - base);
       const int cj = cj_nx;
       const int vj = __builtin_bit_cast(int, vj_nx);
       cj_nx = 0; vj_nx = 0.f;
-      if (base + 64 + tl < end) { cj_nx = a.col[base + 64 + tl]; vj_nx = a.val[base + 64 + tl]; }
+      if (base + 64 + tl < end) { cj_nx = a.col[base + 64 + tl]; if (!VALLESS) vj_nx = a.val[base + 64 + tl]; }
 
       float4 b[LPE];
 #define GCN_Q_GATHER(UU)                                                                         \
       if constexpr (UU < LPE)                                                                    \
         b[UU] = *reinterpret_cast<const float4*>(                                                \
             Bb + (size_t)(__umul24((unsigned)quad_bcast<LPE, UU>(cj), row_bytes) + foff));
-#define GCN_Q_VAL(UU) __builtin_bit_cast(float, quad_bcast<LPE, UU>(vj))
+#define GCN_Q_VAL(UU) (VALLESS ? 1.0f : __builtin_bit_cast(float, quad_bcast<LPE, UU>(vj)))
 #define GCN_Q_ALL(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15)
       // entries past `cnt` carry col = 0, val = 0: they gather row 0 (valid memory) and are
       // masked out below, never multiplied in
@@ -230,8 +234,15 @@ static hipError_t launch_quad(const SpmmArgs& a, int nblocks, bool epi, hipStrea
   for (int t = 0; t < tiles; ++t) {
 #define GCN_QUAD_ARGS a.rowptr, a.col, a.val, a.B, a.C, a.P, a.chunk_row, a.bias, a.nnz_dev, \
                       a.relu, a.nchunks, a.T, a.m, a.nnz, a.k, t, a.accumulate, (a.ldb > 0 ? a.ldb : a.k)
-    if (epi) spmm_quad_kernel<LPE, true><<<dim3(nblocks), dim3(256), 0, s>>>(GCN_QUAD_ARGS);
-    else     spmm_quad_kernel<LPE, false><<<dim3(nblocks), dim3(256), 0, s>>>(GCN_QUAD_ARGS);
+    if constexpr (LPE == 16) {
+      if (a.valless && !epi) {                       // (the value-free variant is only built for the sliced main pass)
+        spmm_quad_kernel<LPE, false, true><<<dim3(nblocks), dim3(256), 0, s>>>(GCN_QUAD_ARGS);
+        continue;
+      }
+    }
+    if (a.valless) return hipErrorInvalidValue;      // a caller bug: B was pre-scaled for a kernel that is not there
+    if (epi) spmm_quad_kernel<LPE, true, false><<<dim3(nblocks), dim3(256), 0, s>>>(GCN_QUAD_ARGS);
+    else     spmm_quad_kernel<LPE, false, false><<<dim3(nblocks), dim3(256), 0, s>>>(GCN_QUAD_ARGS);
 #undef GCN_QUAD_ARGS
   }
   return hipGetLastError();

@@ -163,15 +163,15 @@ def test_main_kernel_families_are_selected_as_documented():
     assert adj.main_kernel(4).startswith("gcn::spmm_narrow_kernel<4,")
     assert adj.main_kernel(8).startswith("gcn::spmm_narrow_kernel<8,")
     assert adj.main_kernel(15) == "gcn::spmm_narrow16_dpp_kernel<false>"
-    assert adj.main_kernel(16) == "gcn::spmm_quad_kernel<4, false>"          # 16 non-zeros per gather
-    assert adj.main_kernel(17) == "gcn::spmm_quad_kernel<16, false>"         # odd widths run at k rounded up to 4
-    assert adj.main_kernel(32) == "gcn::spmm_quad_kernel<16, false>"         # 4 per gather, half the lanes idle
-    assert adj.main_kernel(128) == "gcn::spmm_quad_kernel<16, false>"        # 4 per gather
-    assert adj.main_kernel(128, epilogue=True) == "gcn::spmm_quad_kernel<16, true>"
+    assert adj.main_kernel(16) == "gcn::spmm_quad_kernel<4, false, false>"          # 16 non-zeros per gather
+    assert adj.main_kernel(17) == "gcn::spmm_quad_kernel<16, false, false>"         # odd widths run at k rounded up to 4
+    assert adj.main_kernel(32) == "gcn::spmm_quad_kernel<16, false, false>"         # 4 per gather, half the lanes idle
+    assert adj.main_kernel(128) == "gcn::spmm_quad_kernel<16, false, false>"        # 4 per gather
+    assert adj.main_kernel(128, epilogue=True) == "gcn::spmm_quad_kernel<16, true, false>"
     adj.set_gather_width(1)
     assert adj.main_kernel(16) == "gcn::spmm_narrow16_dpp_kernel<false>"
     adj.set_gather_width(0)
-    assert adj.main_kernel(130) == "gcn::spmm_quad_kernel<16, false>"        # k' = 132
+    assert adj.main_kernel(130) == "gcn::spmm_quad_kernel<16, false, false>"        # k' = 132
     adj.set_gather_width(1)
     assert adj.main_kernel(130).startswith("gcn::spmm_chunk_kernel<1,")      # one non-zero per gather, caller's layout
     assert adj.main_kernel(128).startswith("gcn::spmm_chunk_kernel<1,")
@@ -183,7 +183,7 @@ def test_main_kernel_families_are_selected_as_documented():
     assert short.main_kernel(16) == "gcn::spmm_narrow16_dpp_kernel<false>"
     assert short.main_kernel(130).startswith("gcn::spmm_chunk_kernel<1,")    # and no detour over k' = 132
     short.set_gather_width(4)
-    assert short.main_kernel(128) == "gcn::spmm_quad_kernel<16, false>"
+    assert short.main_kernel(128) == "gcn::spmm_quad_kernel<16, false, false>"
     adj.set_tile_cols(256)
     assert adj.main_kernel(256).startswith("gcn::spmm_chunk_kernel<4,")
     adj.set_tile_cols(128)
@@ -625,3 +625,34 @@ def test_autotune_keeps_the_faster_of_sliced_and_unsliced_and_the_result():
     assert adj.num_slices == next(iter(timings))              # the fastest one stays configured
     after = adj.matmul_raw(B)
     assert float((after - before).abs().max() / before.abs().max()) <= 1e-6
+
+
+def test_value_free_sliced_pass_for_normalised_adjacencies():
+    """Â = D^-1/2 (A+I) D^-1/2 has values u[r]*u[c]: the sliced main pass then runs without its value
+    stream on B scaled by u (gcn_spmm_plan_enable_slicing detects it).  Same result to 1e-5; any other
+    value pattern — even one perturbed entry — keeps the ordinary kernel."""
+    n = 17000                                           # 64-column table > one L2 -> sliced
+    rowptr, col, val = sym_norm_graph(n, 1200000, seed=21)
+    rng = np.random.default_rng(8)
+    for k in (64, 128, 100):                            # 100: the scaling rides on the row-padding copy
+        B = rng.standard_normal((n, k)).astype(np.float32)
+        bias = rng.standard_normal(k).astype(np.float32)
+        adj = _adj(rowptr, col, val, n, n)
+        assert adj.num_slices >= 2 and adj.main_kernel(k) == "gcn::spmm_quad_kernel<16, false, true>"
+        Bd = torch.from_numpy(B).to(_dev())
+        Cref = oracle_spmm(rowptr, col, val, B)
+        assert rel_err(adj.matmul_raw(Bd).cpu().numpy(), Cref) <= TOL
+        Ce = adj.matmul_raw(Bd, bias=torch.from_numpy(bias).to(_dev()), relu=True).cpu().numpy()
+        assert rel_err(Ce, np.maximum(Cref + bias, 0)) <= TOL
+        assert torch.equal(adj.matmul_raw(Bd), adj.matmul_raw(Bd))          # reproducible
+    # one entry off by 1e-4 relative: no longer rank-1 -> the ordinary kernel, and the right answer
+    val2 = val.copy(); val2[len(val2) // 2] *= 1.0001
+    adj2 = _adj(rowptr, col, val2, n, n)
+    assert adj2.num_slices >= 2 and adj2.main_kernel(128) == "gcn::spmm_quad_kernel<16, false, false>"
+    B = rng.standard_normal((n, 128)).astype(np.float32)
+    assert rel_err(adj2.matmul_raw(torch.from_numpy(B).to(_dev())).cpu().numpy(), oracle_spmm(rowptr, col, val2, B)) <= TOL
+    # arbitrary weights
+    val3 = (rng.random(len(val)) + 0.1).astype(np.float32)
+    adj3 = _adj(rowptr, col, val3, n, n)
+    assert adj3.main_kernel(128) == "gcn::spmm_quad_kernel<16, false, false>"
+    assert rel_err(adj3.matmul_raw(torch.from_numpy(B).to(_dev())).cpu().numpy(), oracle_spmm(rowptr, col, val3, B)) <= TOL
