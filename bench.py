@@ -159,8 +159,16 @@ def main():
         launches_per_step = 1
     else:
         sim = args.sim_world if (world == 1 and args.sim_world > 1) else 0
+        # Â = D^-1/2 (A+I) D^-1/2: its values factor as u[r]·u[c] with u = sqrt(diag Â); a row block with
+        # renumbered columns cannot see that by itself, so the factor travels with the partition
+        rows_of = torch.repeat_interleave(torch.arange(n, device=dev), (rowptr[1:] - rowptr[:-1]).long())
+        on_diag = rows_of == col.long()
+        u = torch.zeros(n, device=dev)
+        u[rows_of[on_diag]] = val[on_diag].sqrt()
+        del rows_of, on_diag
         shard = RowShardedAdjacency(rowptr, col, val, n, rank, sim or world,
-                                    lambda rp, ci, va, shape: gcn_amd.CsrAdjacency(rp, ci, va, shape, chunk_nnz=args.chunk))
+                                    lambda rp, ci, va, shape: gcn_amd.CsrAdjacency(rp, ci, va, shape, chunk_nnz=args.chunk),
+                                    value_factor=u)
         if sim:
             shard.collective = False
         # column planes of 64: the RCCL all-gather of one plane overlaps the SpMM of the next

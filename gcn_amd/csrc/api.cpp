@@ -38,7 +38,8 @@ struct gcn_spmm_plan {
   int* vchunk_row;              // [nchunks] rows of the virtual CSR
   float* cv;                    // partial outputs [S*m x k], grow-only
   size_t cv_bytes;
-  float* u;                     // [n] factor of rank-1 values (val[r,c] = u[r]*u[c]), null when they are not
+  float* u_row;                 // [m], [n]: factors of rank-1 values (val[r,c] = u_row[r]*u_col[c]); null when
+  float* u_col;                 // the values do not factor (u_col == u_row for a square normalised adjacency)
   float* bpad;                  // B re-laid with rows padded to whole 128-byte lines (odd k), grow-only
   size_t bpad_bytes;
   float* cpad;                  // result with k rounded up to a multiple of 4 (k % 4 != 0), grow-only
@@ -241,7 +242,7 @@ int gcn_spmm_plan_create(gcn_spmm_plan_t** out, const int32_t* rowptr_dev, int32
   p->chunk_row = nullptr; p->ws = nullptr; p->ws_bytes = 0; p->cu_count = cu;
   p->prof_cap = p->prof_n = 0;
   p->tile_cols = 0;
-  p->u = nullptr;
+  p->u_row = p->u_col = nullptr;
   p->bpad = nullptr; p->bpad_bytes = 0;
   p->cpad = nullptr; p->cpad_bytes = 0;
   p->blocks_per_cu = 32;
@@ -260,6 +261,12 @@ int gcn_spmm_plan_create(gcn_spmm_plan_t** out, const int32_t* rowptr_dev, int32
   return GCN_OK;
 }
 
+static void free_factors(gcn_spmm_plan* p) {
+  if (p->u_col && p->u_col != p->u_row) (void)hipFree(p->u_col);
+  if (p->u_row) (void)hipFree(p->u_row);
+  p->u_row = p->u_col = nullptr;
+}
+
 int gcn_spmm_plan_destroy(gcn_spmm_plan_t* p) {
   if (!p) return GCN_OK;
   if (p->chunk_row) (void)hipFree(p->chunk_row);
@@ -269,7 +276,7 @@ int gcn_spmm_plan_destroy(gcn_spmm_plan_t* p) {
   if (p->vval) (void)hipFree(p->vval);
   if (p->vchunk_row) (void)hipFree(p->vchunk_row);
   if (p->cv) (void)hipFree(p->cv);
-  if (p->u) (void)hipFree(p->u);
+  free_factors(p);
   if (p->bpad) (void)hipFree(p->bpad);
   if (p->cpad) (void)hipFree(p->cpad);
   {
@@ -360,7 +367,10 @@ static int spmm_impl(gcn_spmm_plan_t* p, const int32_t* rowptr, const int32_t* c
     a.ldb = b_ld;                                      // already re-laid by the caller (odd-width path)
   } else if (p->nnz > 0) {
     const int ldb = padded_ldb(p->n, k);
-    if (sliced && p->u && p->panel_R == 0) {
+    // (the scaled copy of B costs 2*n*k*4 bytes of traffic whatever the matrix; the value stream it saves is
+    //  4 bytes per non-zero plus instructions — measured break-even near 65 non-zeros per column of the
+    //  block: the rank-0 share of an 8-way partition of the Reddit-shaped graph (62 per column) does not gain)
+    if (sliced && p->u_row && p->panel_R == 0 && p->nnz / p->n >= 96) {
       gcn::SpmmArgs t = a;                             // the launch as the sliced branch below will issue it
       t.B = nullptr; t.C = nullptr; t.bias = nullptr; t.relu = 0;
       t.m = p->S * p->m; t.ldb = ldb; t.tile_cols = p->tile_cols ? p->tile_cols : 64;
@@ -370,7 +380,7 @@ static int spmm_impl(gcn_spmm_plan_t* p, const int32_t* rowptr, const int32_t* c
     if (ldb != k || valless) {
       const int st = grow(p->bpad, p->bpad_bytes, sizeof(float) * (size_t)p->n * (size_t)ldb);
       if (st != GCN_OK) return st;
-      if (gcn::launch_pad_rows(p->bpad, B, p->n, k, ldb, (hipStream_t)stream, valless ? p->u : nullptr) != hipSuccess)
+      if (gcn::launch_pad_rows(p->bpad, B, p->n, k, ldb, (hipStream_t)stream, valless ? p->u_col : nullptr) != hipSuccess)
         return GCN_ERR_HIP;
       a.B = p->bpad;
       a.ldb = ldb;
@@ -441,7 +451,7 @@ static int spmm_impl(gcn_spmm_plan_t* p, const int32_t* rowptr, const int32_t* c
     a.rowptr = p->vrowptr; a.col = p->vcol; a.val = p->vval; a.chunk_row = p->vchunk_row;
     a.C = p->cv; a.m = p->S * p->m; a.bias = nullptr; a.relu = 0;
     const float* rowscale = nullptr;
-    if (valless) { a.valless = 1; a.val = nullptr; rowscale = p->u; }   // B was scaled by u above
+    if (valless) { a.valless = 1; a.val = nullptr; rowscale = p->u_row; }   // B was scaled by u_col above
     if (gcn::launch_spmm(a, p->cu_count, (hipStream_t)stream) != hipSuccess) return GCN_ERR_HIP;
     return gcn::launch_slice_reduce(p->cv, C, bias, relu ? 1 : 0, p->m, p->S, k,
                                     (hipStream_t)stream, 0, rowscale) == hipSuccess ? GCN_OK : GCN_ERR_HIP;
@@ -455,8 +465,6 @@ static void free_slicing(gcn_spmm_plan* p) {
   if (p->vval) (void)hipFree(p->vval);
   if (p->vchunk_row) (void)hipFree(p->vchunk_row);
   if (p->cv) (void)hipFree(p->cv);
-  if (p->u) (void)hipFree(p->u);
-  p->u = nullptr;
   p->vrowptr = p->vcol = p->vchunk_row = nullptr; p->vval = nullptr; p->cv = nullptr;
   p->cv_bytes = 0; p->S = 0;
 }
@@ -497,18 +505,45 @@ int gcn_spmm_plan_enable_slicing(gcn_spmm_plan_t* p, const int32_t* rowptr, cons
   // Normalised adjacencies (D^-1/2 (A+I) D^-1/2) have values u[r]*u[c]: when every stored entry matches
   // that to 4 ulp the sliced main pass can run without its value stream (spmm_quad.hip, VALLESS) on a
   // B whose rows were scaled by u, with the row factor applied in the slice reduction.
-  if (p->m == p->n && valless_enabled()) {
-    if (hipMalloc((void**)&p->u, sizeof(float) * (size_t)p->n) != hipSuccess) { p->u = nullptr; return GCN_OK; }
+  if (p->m == p->n && valless_enabled() && !p->u_row) {          // (factors given by the caller stay)
+    float* u = nullptr;
+    if (hipMalloc((void**)&u, sizeof(float) * (size_t)p->n) != hipSuccess) return GCN_OK;
     int ok = 0;
-    if (gcn::detect_rank1_values(rowptr, col, val, p->n, p->u, &ok, (hipStream_t)stream) != hipSuccess || !ok) {
-      (void)hipFree(p->u);
-      p->u = nullptr;
-    }
+    if (gcn::detect_rank1_values(rowptr, col, val, p->n, u, &ok, (hipStream_t)stream) != hipSuccess || !ok)
+      (void)hipFree(u);
+    else
+      p->u_row = p->u_col = u;
   }
   return GCN_OK;
 }
 
 int32_t gcn_spmm_plan_num_slices(const gcn_spmm_plan_t* p) { return p ? p->S : -1; }
+
+int gcn_spmm_plan_set_value_factors(gcn_spmm_plan_t* p, const int32_t* rowptr, const int32_t* col,
+                                    const float* val, const float* u_row, const float* u_col, void* stream) {
+  if (!p) return GCN_ERR_INVALID_ARG;
+  free_factors(p);
+  if (!u_row && !u_col) return GCN_OK;                              // (null, null): forget the factors
+  if (!u_row || !u_col || !rowptr || (p->nnz > 0 && (!col || !val))) return GCN_ERR_INVALID_ARG;
+  if (p->m == 0 || p->nnz == 0 || !valless_enabled()) return GCN_OK;
+  int ok = 0;
+  if (gcn::verify_value_factors(rowptr, col, val, u_row, u_col, p->m, &ok, (hipStream_t)stream) != hipSuccess)
+    return GCN_ERR_HIP;
+  if (!ok) return GCN_ERR_INVALID_ARG;                              // some entry is not u_row[r]*u_col[c]
+  float *ur = nullptr, *uc = nullptr;
+  if (hipMalloc((void**)&ur, sizeof(float) * (size_t)p->m) != hipSuccess) return GCN_ERR_ALLOC;
+  if (hipMalloc((void**)&uc, sizeof(float) * (size_t)p->n) != hipSuccess) { (void)hipFree(ur); return GCN_ERR_ALLOC; }
+  if (hipMemcpyAsync(ur, u_row, sizeof(float) * (size_t)p->m, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess ||
+      hipMemcpyAsync(uc, u_col, sizeof(float) * (size_t)p->n, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess ||
+      hipStreamSynchronize((hipStream_t)stream) != hipSuccess) {
+    (void)hipFree(ur); (void)hipFree(uc);
+    return GCN_ERR_HIP;
+  }
+  p->u_row = ur; p->u_col = uc;
+  return GCN_OK;
+}
+
+int32_t gcn_spmm_plan_has_value_factors(const gcn_spmm_plan_t* p) { return p ? (p->u_row != nullptr) : -1; }
 
 static void free_panels(gcn_spmm_plan* p) {
   void* ptrs[] = {p->panel_w0, p->pin_rowptr, p->pin_off, p->pin_val, p->pout_rowptr, p->pout_col,
@@ -640,7 +675,7 @@ int gcn_spmm_plan_main_kernel(const gcn_spmm_plan_t* p, int32_t k, int32_t epilo
     a.relu = 0;
   } else {
     if (const int ldb = padded_ldb(p->n, k); ldb != k) a.ldb = ldb;
-    if (sliced && p->u) a.valless = gcn::spmm_will_use_quad(a) && gcn::spmm_quad_lanes(k) == 16;   // as spmm_impl decides
+    if (sliced && p->u_row && p->nnz / p->n >= 96) a.valless = gcn::spmm_will_use_quad(a) && gcn::spmm_quad_lanes(k) == 16;   // as spmm_impl decides
   }
   gcn::describe_main_kernel(a, buf, (size_t)buflen);
   return GCN_OK;

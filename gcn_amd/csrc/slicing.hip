@@ -213,14 +213,14 @@ __global__ void rank1_diag_kernel(const int* __restrict__ rowptr, const int* __r
 // every stored entry within 4 ulp of u[r] * u[c]; one wave per row
 __global__ void __launch_bounds__(256)
 rank1_check_kernel(const int* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ val,
-                   const float* __restrict__ u, int n, int* __restrict__ fail) {
+                   const float* __restrict__ u, const float* __restrict__ ucol, int n, int* __restrict__ fail) {
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int nw = gridDim.x * 4;
   for (int r = wave; r < n; r += nw) {
     const float ur = u[r];
     for (int e = rowptr[r] + lane; e < rowptr[r + 1]; e += 64) {
-      const float want = ur * u[col[e]];
+      const float want = ur * ucol[col[e]];
       if (!(fabsf(val[e] - want) <= 4.8e-7f * fabsf(val[e]))) *fail = 1;
     }
   }
@@ -239,7 +239,30 @@ hipError_t detect_rank1_values(const int* rowptr, const int* col, const float* v
     rank1_diag_kernel<<<(n + 255) / 256, 256, 0, st>>>(rowptr, col, val, n, u_out, fail);
     int nb = (n + 3) / 4;
     if (nb > 16384) nb = 16384;
-    rank1_check_kernel<<<nb, 256, 0, st>>>(rowptr, col, val, u_out, n, fail);
+    rank1_check_kernel<<<nb, 256, 0, st>>>(rowptr, col, val, u_out, u_out, n, fail);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(&h, fail, sizeof(int), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  (void)hipFree(fail);
+  if (e == hipSuccess) *ok_host = h ? 0 : 1;
+  return e;
+}
+
+// caller-supplied factors: val[r, c] == u_row[r] * u_col[c] (4 ulp) for every stored entry of the m-row matrix?
+hipError_t verify_value_factors(const int* rowptr, const int* col, const float* val, const float* u_row,
+                                const float* u_col, int m, int* ok_host, hipStream_t st) {
+  *ok_host = 0;
+  if (m <= 0) return hipSuccess;
+  int* fail = nullptr;
+  hipError_t e = hipMalloc((void**)&fail, sizeof(int));
+  if (e != hipSuccess) return e;
+  int h = 1;
+  e = hipMemsetAsync(fail, 0, sizeof(int), st);
+  if (e == hipSuccess) {
+    int nb = (m + 3) / 4;
+    if (nb > 16384) nb = 16384;
+    rank1_check_kernel<<<nb, 256, 0, st>>>(rowptr, col, val, u_row, u_col, m, fail);
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipMemcpyAsync(&h, fail, sizeof(int), hipMemcpyDeviceToHost, st);

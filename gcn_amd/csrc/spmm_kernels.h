@@ -89,6 +89,8 @@ hipError_t build_sliced_csr(const int* rowptr, const int* col, const float* val,
 hipError_t launch_slice_reduce(const float* Cv, float* C, const float* bias, int relu, int m, int S,
                                int k, hipStream_t st, int accumulate = 0, const float* rowscale = nullptr);
 // values factor as u[r]*u[c]?  u_out[n] (device), *ok_host = 1 when every stored entry matches within 4 ulp
+hipError_t verify_value_factors(const int* rowptr, const int* col, const float* val, const float* u_row,
+                                const float* u_col, int m, int* ok_host, hipStream_t st);
 hipError_t detect_rank1_values(const int* rowptr, const int* col, const float* val, int n, float* u_out,
                                int* ok_host, hipStream_t st);
 

@@ -39,7 +39,7 @@ class RowShardedAdjacency:
     inject an oracle-backed stand-in (the product path has no CPU compute).
     """
 
-    def __init__(self, rowptr, col, val, n, rank, world, make_local, balance="nnz"):
+    def __init__(self, rowptr, col, val, n, rank, world, make_local, balance="nnz", value_factor=None):
         rowptr_h = rowptr.detach().cpu().numpy().astype(np.int64)
         self.n, self.rank, self.world = int(n), int(rank), int(world)
         self.collective = True     # False = compute this rank's block only (single-GPU rehearsal of rank r of W)
@@ -60,7 +60,14 @@ class RowShardedAdjacency:
         self._local_args = (local_rowptr, pcol.to(torch.int32), val[e_lo:e_hi].contiguous(),
                             (self.rows, self.world * self.max_rows))
         self._make_local = make_local
-        self.local = make_local(*self._local_args)
+        # value_factor: u [n] with Â[r, c] = u[r]·u[c] (u = D^-1/2 of a normalised adjacency).  The row block
+        # with renumbered columns still factors — as u[rows] x u in the padded numbering — and telling the
+        # operator so lets its sliced main pass drop the value stream (CsrAdjacency.set_value_factors)
+        self._factors = None
+        if value_factor is not None:
+            u = value_factor.to(device=device, dtype=torch.float32)
+            self._factors = (u[self.row_lo:self.row_hi].contiguous(), self.to_padded(u[:, None])[:, 0].contiguous())
+        self.local = self._new_local()
         self._bounds_t = bounds_t
 
     # global [n, k] -> padded [world*max_rows, k]
@@ -92,7 +99,16 @@ class RowShardedAdjacency:
     def another_local(self):
         """A second operator over the same row block (own plan, own workspaces) — what lets two
         SpMMs of this block run on different streams at the same time (PipelinedAggregation)."""
-        return self._make_local(*self._local_args)
+        return self._new_local()
+
+    def _new_local(self):
+        local = self._make_local(*self._local_args)
+        if self._factors is not None and hasattr(local, "set_value_factors"):
+            try:
+                local.set_value_factors(*self._factors)
+            except Exception:                       # the values do not factor that way: keep reading them
+                self._factors = None
+        return local
 
     def layer_async(self, H_padded, out_padded, group=None, local=None):
         """Like layer(), but the all-gather is only ENQUEUED (on the communicator's stream, behind

@@ -140,6 +140,27 @@ class CsrAdjacency:
                                                           _ptr(self.val), int(slices), _stream_ptr(self.device))
         _lib.check(st, "gcn_spmm_plan_enable_slicing")
 
+    def set_value_factors(self, u_row, u_col):
+        """Declare val[r, c] == u_row[r] * u_col[c] (checked on the device; GcnAmdError if an entry does not
+        factor): lets the sliced main pass run without its value stream.  Square normalised adjacencies
+        are detected automatically; this is for row blocks / renumbered columns.  (None, None) forgets."""
+        if u_row is None and u_col is None:
+            _lib.check(_lib.load().gcn_spmm_plan_set_value_factors(self.plan, None, None, None, None, None,
+                                                                   _stream_ptr(self.device)), "gcn_spmm_plan_set_value_factors")
+            return
+        ur = u_row.to(device=self.device, dtype=torch.float32).contiguous()
+        uc = u_col.to(device=self.device, dtype=torch.float32).contiguous()
+        if ur.numel() != self.m or uc.numel() != self.n:
+            raise ValueError("u_row needs m entries and u_col n entries")
+        with torch.cuda.device(self.device):
+            st = _lib.load().gcn_spmm_plan_set_value_factors(self.plan, _ptr(self.rowptr), _ptr(self.col), _ptr(self.val),
+                                                             _ptr(ur), _ptr(uc), _stream_ptr(self.device))
+        _lib.check(st, "gcn_spmm_plan_set_value_factors")
+
+    @property
+    def has_value_factors(self):
+        return bool(_lib.load().gcn_spmm_plan_has_value_factors(self.plan))
+
     @property
     def num_slices(self):
         return int(_lib.load().gcn_spmm_plan_num_slices(self.plan))

@@ -125,6 +125,20 @@ int gcn_spmm_plan_enable_slicing(gcn_spmm_plan_t* plan, const int32_t* rowptr_de
                                  int32_t slices, void* stream);
 int32_t gcn_spmm_plan_num_slices(const gcn_spmm_plan_t* plan);
 
+/* Rank-1 values.  When every stored value is u_row[r] * u_col[c] — the GCN normalisation
+ * D^-1/2 (A+I) D^-1/2 has u = D^-1/2 — the sliced main pass runs WITHOUT its value stream (5 % of the
+ * bytes it moves, and they are its time): B is gathered from a copy whose rows were scaled by u_col and
+ * the finished rows are scaled by u_row in the slice reduction; results stay within the 1e-5 contract
+ * (each term carries one more rounding).  gcn_spmm_plan_enable_slicing detects this by itself for SQUARE
+ * matrices with a stored diagonal (u = sqrt(diag)); for anything else — e.g. a row block of such a
+ * matrix with renumbered columns — hand the factors over here (device arrays [m] and [n], copied).
+ * Every entry is checked (4 ulp): GCN_ERR_INVALID_ARG if one does not factor.  (NULL, NULL) forgets the
+ * factors.  The matrix arrays must be the ones the plan was created for. */
+int gcn_spmm_plan_set_value_factors(gcn_spmm_plan_t* plan, const int32_t* rowptr_dev, const int32_t* col_dev,
+                                    const float* val_dev, const float* u_row_dev, const float* u_col_dev,
+                                    void* stream);
+int32_t gcn_spmm_plan_has_value_factors(const gcn_spmm_plan_t* plan);   /* 1 / 0 */
+
 /* LDS-staged row panels (optional): for matrices whose non-zeros sit near the diagonal (community
  * graphs after Rabbit / RCM / Gorder renumbering) a workgroup stages the feature rows of its panel's
  * column window (512 rows x 64 columns = 128 KiB of LDS) once and sums the in-window non-zeros

@@ -10,6 +10,7 @@ import os
 
 import numpy as np
 import pytest
+import scipy.sparse as sp
 import torch
 
 import gcn_amd
@@ -656,3 +657,33 @@ def test_value_free_sliced_pass_for_normalised_adjacencies():
     adj3 = _adj(rowptr, col, val3, n, n)
     assert adj3.main_kernel(128) == "gcn::spmm_quad_kernel<16, false, false>"
     assert rel_err(adj3.matmul_raw(torch.from_numpy(B).to(_dev())).cpu().numpy(), oracle_spmm(rowptr, col, val3, B)) <= TOL
+
+
+def test_explicit_value_factors_on_a_row_block_with_renumbered_columns():
+    """a row block of Â with permuted column numbering still has values u_row[r]*u_col[c]: handed over
+    explicitly (gcn_spmm_plan_set_value_factors) the sliced pass drops the value stream; factors that do
+    not match are refused"""
+    n = 20000
+    rowptr, col, val = sym_norm_graph(n, 1500000, seed=5)
+    A = sp.csr_matrix((val, col, rowptr), shape=(n, n))
+    u = np.sqrt(A.diagonal()).astype(np.float32)
+    perm = np.random.default_rng(2).permutation(n)              # new column id of old column c
+    lo, hi = 3000, 18000                                        # 15 000 rows x ~150: > 96 non-zeros per column
+    Ablk = A[lo:hi][:, np.argsort(perm)].tocsr(); Ablk.sort_indices()   # column j of the block = old column argsort(perm)[j]
+    u_col = u[np.argsort(perm)]
+    rp, ci, va = Ablk.indptr.astype(np.int32), Ablk.indices.astype(np.int32), Ablk.data.astype(np.float32)
+    adj = _adj(rp, ci, va, hi - lo, n, slices=2)                # 75 non-zeros per virtual row: the quad kernel
+    assert not adj.has_value_factors                            # rectangular: nothing to detect
+    assert adj.main_kernel(128) == "gcn::spmm_quad_kernel<16, false, false>"
+    B = np.random.default_rng(3).standard_normal((n, 128)).astype(np.float32)
+    Bd = torch.from_numpy(B).to(_dev())
+    plain = adj.matmul_raw(Bd).cpu().numpy()
+    adj.set_value_factors(torch.from_numpy(u[lo:hi]), torch.from_numpy(u_col))
+    assert adj.has_value_factors and adj.main_kernel(128) == "gcn::spmm_quad_kernel<16, false, true>"
+    fast = adj.matmul_raw(Bd).cpu().numpy()
+    Cref = oracle_spmm(rp, ci, va, B)
+    assert rel_err(plain, Cref) <= TOL and rel_err(fast, Cref) <= TOL
+    with pytest.raises(Exception):
+        adj.set_value_factors(torch.from_numpy(u[lo:hi] * 1.001), torch.from_numpy(u_col))
+    assert not adj.has_value_factors                            # a refused hand-over leaves none behind
+    assert rel_err(adj.matmul_raw(Bd).cpu().numpy(), Cref) <= TOL
