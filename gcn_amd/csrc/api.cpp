@@ -307,10 +307,12 @@ static int grow(float*& buf, size_t& have, size_t need) {
   return GCN_OK;
 }
 
-// b_ld: row stride of B in floats when the caller of this function has already re-laid it, 0 = k
+// b_ld: row stride of B in floats when the caller of this function has already re-laid it, 0 = k;
+// b_scaled: that copy's rows are already scaled by u_col (value-free pass)
 static int spmm_impl(gcn_spmm_plan_t* p, const int32_t* rowptr, const int32_t* col, const float* val,
-                     const float* B, int b_ld, float* C, const float* bias, int32_t relu, int32_t k,
+                     const float* B, int b_ld, bool b_scaled, float* C, const float* bias, int32_t relu, int32_t k,
                      void* stream);
+static bool valless_pays(const gcn_spmm_plan_t* p, const gcn::SpmmArgs& base, int k, int ldb);
 
 int gcn_spmm_csr_f32_bias_relu(gcn_spmm_plan_t* p, const int32_t* rowptr, const int32_t* col,
                                const float* val, const float* B, float* C, const float* bias,
@@ -330,18 +332,35 @@ int gcn_spmm_csr_f32_bias_relu(gcn_spmm_plan_t* p, const int32_t* rowptr, const 
       int st = grow(p->bpad, p->bpad_bytes, sizeof(float) * (size_t)p->n * (size_t)ldb);
       if (st == GCN_OK) st = grow(p->cpad, p->cpad_bytes, sizeof(float) * (size_t)p->m * (size_t)kp);
       if (st != GCN_OK) return st;
-      if (gcn::launch_pad_rows(p->bpad, B, p->n, k, ldb, (hipStream_t)stream) != hipSuccess) return GCN_ERR_HIP;
-      st = spmm_impl(p, rowptr, col, val, p->bpad, ldb, p->cpad, nullptr, 0, kp, stream);
+      const bool scaled = valless_pays(p, gcn::SpmmArgs{}, kp, ldb);       // the copy can carry the u_col scaling
+      if (gcn::launch_pad_rows(p->bpad, B, p->n, k, ldb, (hipStream_t)stream, scaled ? p->u_col : nullptr) != hipSuccess)
+        return GCN_ERR_HIP;
+      st = spmm_impl(p, rowptr, col, val, p->bpad, ldb, scaled, p->cpad, nullptr, 0, kp, stream);
       if (st != GCN_OK) return st;
       return gcn::launch_unpad_rows(C, p->cpad, bias, relu ? 1 : 0, p->m, k, kp, (hipStream_t)stream) == hipSuccess
                  ? GCN_OK : GCN_ERR_HIP;
     }
   }
-  return spmm_impl(p, rowptr, col, val, B, 0, C, bias, relu, k, stream);
+  return spmm_impl(p, rowptr, col, val, B, 0, false, C, bias, relu, k, stream);
+}
+
+// would the sliced launch of a k-wide SpMM run the value-free quad kernel (and is the scaled copy worth it)?
+static bool valless_pays(const gcn_spmm_plan_t* p, const gcn::SpmmArgs& base, int k, int ldb) {
+  const bool sliced = p->S > 0 && p->nnz > 0 && k >= slice_min_k();
+  // (the scaled copy of B costs 2*n*k*4 bytes of traffic whatever the matrix; the value stream it saves is
+  //  4 bytes per non-zero plus instructions — measured break-even near 65 non-zeros per column of the
+  //  block: the rank-0 share of an 8-way partition of the Reddit-shaped graph (62 per column) does not gain)
+  if (!sliced || !p->u_row || p->panel_R != 0 || p->nnz / p->n < 96) return false;
+  gcn::SpmmArgs t = base;                              // the launch as the sliced branch will issue it
+  t.B = nullptr; t.C = nullptr; t.bias = nullptr; t.relu = 0; t.k = k; t.nnz = p->nnz; t.n = p->n;
+  t.nchunks_grid = p->nchunks; t.T = p->T; t.nnz_dev = nullptr;
+  t.m = p->S * p->m; t.ldb = ldb; t.tile_cols = p->tile_cols ? p->tile_cols : 64;
+  t.gather_width = p->gather_width;
+  return gcn::spmm_will_use_quad(t) && gcn::spmm_quad_lanes(k) == 16;
 }
 
 static int spmm_impl(gcn_spmm_plan_t* p, const int32_t* rowptr, const int32_t* col, const float* val,
-                     const float* B, int b_ld, float* C, const float* bias, int32_t relu, int32_t k,
+                     const float* B, int b_ld, bool b_scaled, float* C, const float* bias, int32_t relu, int32_t k,
                      void* stream) {
   {
     std::lock_guard<std::mutex> lk(g_mu);
@@ -364,19 +383,11 @@ static int spmm_impl(gcn_spmm_plan_t* p, const int32_t* rowptr, const int32_t* c
   // value-free pass (values u[r]*u[c], sliced matrix, four-per-gather kernel): B' = diag(u) B.
   bool valless = false;
   if (b_ld > 0) {
-    a.ldb = b_ld;                                      // already re-laid by the caller (odd-width path)
+    a.ldb = b_ld;                                      // already re-laid (and maybe scaled) by the caller (odd-width path)
+    valless = b_scaled;
   } else if (p->nnz > 0) {
     const int ldb = padded_ldb(p->n, k);
-    // (the scaled copy of B costs 2*n*k*4 bytes of traffic whatever the matrix; the value stream it saves is
-    //  4 bytes per non-zero plus instructions — measured break-even near 65 non-zeros per column of the
-    //  block: the rank-0 share of an 8-way partition of the Reddit-shaped graph (62 per column) does not gain)
-    if (sliced && p->u_row && p->panel_R == 0 && p->nnz / p->n >= 96) {
-      gcn::SpmmArgs t = a;                             // the launch as the sliced branch below will issue it
-      t.B = nullptr; t.C = nullptr; t.bias = nullptr; t.relu = 0;
-      t.m = p->S * p->m; t.ldb = ldb; t.tile_cols = p->tile_cols ? p->tile_cols : 64;
-      t.gather_width = p->gather_width;
-      valless = gcn::spmm_will_use_quad(t) && gcn::spmm_quad_lanes(k) == 16;
-    }
+    valless = valless_pays(p, a, k, ldb);
     if (ldb != k || valless) {
       const int st = grow(p->bpad, p->bpad_bytes, sizeof(float) * (size_t)p->n * (size_t)ldb);
       if (st != GCN_OK) return st;
@@ -673,9 +684,10 @@ int gcn_spmm_plan_main_kernel(const gcn_spmm_plan_t* p, int32_t k, int32_t epilo
     a.k = (k + 3) / 4 * 4;                             // odd widths run at k rounded up to 4 (see gcn_spmm_csr_f32_bias_relu)
     a.ldb = (a.k + 31) / 32 * 32;
     a.relu = 0;
+    a.valless = valless_pays(p, a, a.k, a.ldb);
   } else {
     if (const int ldb = padded_ldb(p->n, k); ldb != k) a.ldb = ldb;
-    if (sliced && p->u_row && p->nnz / p->n >= 96) a.valless = gcn::spmm_will_use_quad(a) && gcn::spmm_quad_lanes(k) == 16;   // as spmm_impl decides
+    a.valless = valless_pays(p, a, k, a.ldb > 0 ? a.ldb : k);   // as spmm_impl decides
   }
   gcn::describe_main_kernel(a, buf, (size_t)buflen);
   return GCN_OK;

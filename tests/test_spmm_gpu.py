@@ -635,7 +635,7 @@ def test_value_free_sliced_pass_for_normalised_adjacencies():
     n = 17000                                           # 64-column table > one L2 -> sliced
     rowptr, col, val = sym_norm_graph(n, 1200000, seed=21)
     rng = np.random.default_rng(8)
-    for k in (64, 128, 100):                            # 100: the scaling rides on the row-padding copy
+    for k in (64, 128, 100, 41, 47):                    # 100: the scaling rides on the row-padding copy; 41, 47: on the odd-width copy
         B = rng.standard_normal((n, k)).astype(np.float32)
         bias = rng.standard_normal(k).astype(np.float32)
         adj = _adj(rowptr, col, val, n, n)
