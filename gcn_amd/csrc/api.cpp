@@ -38,6 +38,9 @@ struct gcn_spmm_plan {
   int* vchunk_row;              // [nchunks] rows of the virtual CSR
   float* cv;                    // partial outputs [S*m x k], grow-only
   size_t cv_bytes;
+  int *vrowptr16, *vchunk_row16;  // 16-bit column stream of the sliced CSR (value-free pass): [S*m+1], [nchunks16]
+  unsigned short* vcol16;       // [nnz16] offsets inside the slice, 0xFFFF = padding marker
+  int nnz16, nchunks16, start16[9];
   float* u_row;                 // [m], [n]: factors of rank-1 values (val[r,c] = u_row[r]*u_col[c]); null when
   float* u_col;                 // the values do not factor (u_col == u_row for a square normalised adjacency)
   float* bpad;                  // B re-laid with rows padded to whole 128-byte lines (odd k), grow-only
@@ -106,6 +109,12 @@ int auto_tile_cols(long long n, int k) {
 // value-free sliced main pass for matrices whose values factor as u[r]*u[c] (development knob GCN_AMD_VALLESS=0: off)
 static bool valless_enabled() {
   static const bool v = [] { const char* e = std::getenv("GCN_AMD_VALLESS"); return !e || e[0] != '0'; }();
+  return v;
+}
+
+// 16-bit column stream in the value-free pass (development knob GCN_AMD_COL16=0: off)
+static bool col16_enabled() {
+  static const bool v = [] { const char* e = std::getenv("GCN_AMD_COL16"); return !e || e[0] != '0'; }();
   return v;
 }
 
@@ -243,6 +252,7 @@ int gcn_spmm_plan_create(gcn_spmm_plan_t** out, const int32_t* rowptr_dev, int32
   p->prof_cap = p->prof_n = 0;
   p->tile_cols = 0;
   p->u_row = p->u_col = nullptr;
+  p->vrowptr16 = p->vchunk_row16 = nullptr; p->vcol16 = nullptr; p->nnz16 = p->nchunks16 = 0;
   p->bpad = nullptr; p->bpad_bytes = 0;
   p->cpad = nullptr; p->cpad_bytes = 0;
   p->blocks_per_cu = 32;
@@ -276,6 +286,9 @@ int gcn_spmm_plan_destroy(gcn_spmm_plan_t* p) {
   if (p->vval) (void)hipFree(p->vval);
   if (p->vchunk_row) (void)hipFree(p->vchunk_row);
   if (p->cv) (void)hipFree(p->cv);
+  if (p->vrowptr16) (void)hipFree(p->vrowptr16);
+  if (p->vchunk_row16) (void)hipFree(p->vchunk_row16);
+  if (p->vcol16) (void)hipFree(p->vcol16);
   free_factors(p);
   if (p->bpad) (void)hipFree(p->bpad);
   if (p->cpad) (void)hipFree(p->cpad);
@@ -294,6 +307,7 @@ int32_t gcn_spmm_plan_chunk_nnz(const gcn_spmm_plan_t* p) { return p ? p->T : -1
 size_t gcn_spmm_plan_workspace_bytes(const gcn_spmm_plan_t* p, int32_t k) {
   if (!p || k <= 0) return 0;
   int chunks = p->nchunks > p->pout_nchunks ? p->nchunks : p->pout_nchunks;
+  if (p->nchunks16 > chunks) chunks = p->nchunks16;
   return sizeof(float) * 2 * (size_t)(chunks > 0 ? chunks : 1) * (size_t)k;
 }
 
@@ -329,11 +343,12 @@ int gcn_spmm_csr_f32_bias_relu(gcn_spmm_plan_t* p, const int32_t* rowptr, const 
       rows_long_enough_for_quad(p, k)) {
     const int kp = (k + 3) / 4 * 4, ldb = (kp + 31) / 32 * 32;
     if ((long long)sizeof(float) * p->n * ldb <= (768LL << 20)) {
-      int st = grow(p->bpad, p->bpad_bytes, sizeof(float) * (size_t)p->n * (size_t)ldb);
+      int st = grow(p->bpad, p->bpad_bytes, sizeof(float) * ((size_t)p->n + 1) * (size_t)ldb);
       if (st == GCN_OK) st = grow(p->cpad, p->cpad_bytes, sizeof(float) * (size_t)p->m * (size_t)kp);
       if (st != GCN_OK) return st;
       const bool scaled = valless_pays(p, gcn::SpmmArgs{}, kp, ldb);       // the copy can carry the u_col scaling
-      if (gcn::launch_pad_rows(p->bpad, B, p->n, k, ldb, (hipStream_t)stream, scaled ? p->u_col : nullptr) != hipSuccess)
+      if (gcn::launch_pad_rows(p->bpad, B, p->n, k, ldb, (hipStream_t)stream, scaled ? p->u_col : nullptr) != hipSuccess ||
+          hipMemsetAsync(p->bpad + (size_t)p->n * ldb, 0, sizeof(float) * (size_t)ldb, (hipStream_t)stream) != hipSuccess)
         return GCN_ERR_HIP;
       st = spmm_impl(p, rowptr, col, val, p->bpad, ldb, scaled, p->cpad, nullptr, 0, kp, stream);
       if (st != GCN_OK) return st;
@@ -389,9 +404,11 @@ static int spmm_impl(gcn_spmm_plan_t* p, const int32_t* rowptr, const int32_t* c
     const int ldb = padded_ldb(p->n, k);
     valless = valless_pays(p, a, k, ldb);
     if (ldb != k || valless) {
-      const int st = grow(p->bpad, p->bpad_bytes, sizeof(float) * (size_t)p->n * (size_t)ldb);
+      // (one row more than B has: the all-zero row the 16-bit stream's padding markers gather)
+      const int st = grow(p->bpad, p->bpad_bytes, sizeof(float) * ((size_t)p->n + 1) * (size_t)ldb);
       if (st != GCN_OK) return st;
-      if (gcn::launch_pad_rows(p->bpad, B, p->n, k, ldb, (hipStream_t)stream, valless ? p->u_col : nullptr) != hipSuccess)
+      if (gcn::launch_pad_rows(p->bpad, B, p->n, k, ldb, (hipStream_t)stream, valless ? p->u_col : nullptr) != hipSuccess ||
+          hipMemsetAsync(p->bpad + (size_t)p->n * ldb, 0, sizeof(float) * (size_t)ldb, (hipStream_t)stream) != hipSuccess)
         return GCN_ERR_HIP;
       a.B = p->bpad;
       a.ldb = ldb;
@@ -462,7 +479,15 @@ static int spmm_impl(gcn_spmm_plan_t* p, const int32_t* rowptr, const int32_t* c
     a.rowptr = p->vrowptr; a.col = p->vcol; a.val = p->vval; a.chunk_row = p->vchunk_row;
     a.C = p->cv; a.m = p->S * p->m; a.bias = nullptr; a.relu = 0;
     const float* rowscale = nullptr;
-    if (valless) { a.valless = 1; a.val = nullptr; rowscale = p->u_row; }   // B was scaled by u_col above
+    if (valless) {                                                          // B was scaled by u_col above
+      a.valless = 1; a.val = nullptr; rowscale = p->u_row;
+      if (p->vcol16) {                                                      // 16-bit column stream, slice-aligned chunks
+        a.rowptr = p->vrowptr16; a.col = reinterpret_cast<const int*>(p->vcol16); a.chunk_row = p->vchunk_row16;
+        a.nnz = p->nnz16; a.nchunks = a.nchunks_grid = p->nchunks16;
+        a.col16 = 1; a.col16_S = p->S; a.col16_w = (p->n + p->S - 1) / p->S;
+        for (int i = 0; i < 9; ++i) a.col16_start[i] = p->start16[i];
+      }
+    }
     if (gcn::launch_spmm(a, p->cu_count, (hipStream_t)stream) != hipSuccess) return GCN_ERR_HIP;
     return gcn::launch_slice_reduce(p->cv, C, bias, relu ? 1 : 0, p->m, p->S, k,
                                     (hipStream_t)stream, 0, rowscale) == hipSuccess ? GCN_OK : GCN_ERR_HIP;
@@ -476,6 +501,10 @@ static void free_slicing(gcn_spmm_plan* p) {
   if (p->vval) (void)hipFree(p->vval);
   if (p->vchunk_row) (void)hipFree(p->vchunk_row);
   if (p->cv) (void)hipFree(p->cv);
+  if (p->vrowptr16) (void)hipFree(p->vrowptr16);
+  if (p->vchunk_row16) (void)hipFree(p->vchunk_row16);
+  if (p->vcol16) (void)hipFree(p->vcol16);
+  p->vrowptr16 = p->vchunk_row16 = nullptr; p->vcol16 = nullptr; p->nnz16 = p->nchunks16 = 0;
   p->vrowptr = p->vcol = p->vchunk_row = nullptr; p->vval = nullptr; p->cv = nullptr;
   p->cv_bytes = 0; p->S = 0;
 }
@@ -513,6 +542,30 @@ int gcn_spmm_plan_enable_slicing(gcn_spmm_plan_t* p, const int32_t* rowptr, cons
     return GCN_ERR_HIP;
   }
   p->S = slices;
+  // 16-bit column stream for the value-free pass (2 instead of 4 index bytes per non-zero across the fabric):
+  // slices at most 65 535 columns wide, at most 8 of them; best effort — without it the 32-bit stream is used
+  if (slices <= 8 && (p->n + slices - 1) / slices <= 65535 && col16_enabled()) {
+    if (hipMalloc((void**)&p->vrowptr16, sizeof(int) * (size_t)(vm + 1)) == hipSuccess) {
+      int nnz16 = 0;
+      if (gcn::build_col16_stream(p->vrowptr, p->vcol, p->m, p->n, slices, p->T, p->vrowptr16, &p->vcol16, &nnz16,
+                                  p->start16, (hipStream_t)stream) == hipSuccess && nnz16 > 0) {
+        p->nnz16 = nnz16;
+        p->nchunks16 = nnz16 / p->T;
+        if (hipMalloc((void**)&p->vchunk_row16, sizeof(int) * (size_t)p->nchunks16) != hipSuccess ||
+            gcn::launch_plan_chunk_rows(p->vrowptr16, (int)vm, p->T, p->nchunks16, p->vchunk_row16,
+                                        (hipStream_t)stream) != hipSuccess ||
+            hipStreamSynchronize((hipStream_t)stream) != hipSuccess) {
+          if (p->vchunk_row16) (void)hipFree(p->vchunk_row16);
+          p->vchunk_row16 = nullptr;
+        }
+      }
+      if (!p->vchunk_row16) {                           // anything failed: drop the 16-bit stream
+        if (p->vcol16) (void)hipFree(p->vcol16);
+        (void)hipFree(p->vrowptr16);
+        p->vcol16 = nullptr; p->vrowptr16 = nullptr; p->nnz16 = p->nchunks16 = 0;
+      }
+    }
+  }
   // Normalised adjacencies (D^-1/2 (A+I) D^-1/2) have values u[r]*u[c]: when every stored entry matches
   // that to 4 ulp the sliced main pass can run without its value stream (spmm_quad.hip, VALLESS) on a
   // B whose rows were scaled by u, with the row factor applied in the slice reduction.
@@ -685,9 +738,11 @@ int gcn_spmm_plan_main_kernel(const gcn_spmm_plan_t* p, int32_t k, int32_t epilo
     a.ldb = (a.k + 31) / 32 * 32;
     a.relu = 0;
     a.valless = valless_pays(p, a, a.k, a.ldb);
+    a.col16 = a.valless && p->vcol16 != nullptr;
   } else {
     if (const int ldb = padded_ldb(p->n, k); ldb != k) a.ldb = ldb;
     a.valless = valless_pays(p, a, k, a.ldb > 0 ? a.ldb : k);   // as spmm_impl decides
+    a.col16 = a.valless && p->vcol16 != nullptr;
   }
   gcn::describe_main_kernel(a, buf, (size_t)buflen);
   return GCN_OK;

@@ -195,6 +195,79 @@ hipError_t launch_slice_reduce(const float* Cv, float* C, const float* bias, int
   return hipGetLastError();
 }
 
+// ---- 16-bit column stream (spmm_quad.hip, COL16) ----
+__global__ void col16_rowptr_kernel(const int* __restrict__ vrowptr, int m, int S, const int* __restrict__ pad_before,
+                                    int* __restrict__ vrowptr16) {
+  const long long vr = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (vr > (long long)S * m) return;
+  const int s = (int)(vr / m);                       // vr == S*m -> s == S: pad_before[S] = all the padding
+  vrowptr16[vr] = vrowptr[vr] + pad_before[s];
+}
+
+// one wave per virtual row: offsets inside the slice, 16 bits each
+__global__ void __launch_bounds__(256)
+col16_scatter_kernel(const int* __restrict__ vrowptr, const int* __restrict__ vcol, const int* __restrict__ vrowptr16,
+                     int m, int S, int w, unsigned short* __restrict__ col16) {
+  const int lane = threadIdx.x & 63;
+  const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long long nw = (long long)gridDim.x * 4;
+  for (long long vr = wave; vr < (long long)S * m; vr += nw) {
+    const int base = (int)(vr / m) * w;
+    const int src = vrowptr[vr], dst = vrowptr16[vr], len = vrowptr[vr + 1] - src;
+    for (int i = lane; i < len; i += 64) col16[dst + i] = (unsigned short)(vcol[src + i] - base);
+  }
+}
+
+hipError_t build_col16_stream(const int* vrowptr, const int* vcol, int m, int n, int S, int T, int* vrowptr16,
+                              unsigned short** col16_out, int* nnz16_host, int* start_host, hipStream_t st) {
+  *col16_out = nullptr;
+  *nnz16_host = 0;
+  const int w = (n + S - 1) / S;
+  if (S < 1 || S > 8 || w > 65535 || m <= 0) return hipErrorInvalidValue;
+  // slice boundaries of the unpadded stream
+  int bounds[9];
+  hipError_t e = hipSuccess;
+  for (int s = 0; s <= S && e == hipSuccess; ++s)
+    e = hipMemcpyAsync(&bounds[s], vrowptr + (size_t)s * m, sizeof(int), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e != hipSuccess) return e;
+  int pad_before[9];
+  long long total = 0;
+  for (int s = 0; s < S; ++s) {
+    pad_before[s] = (int)(total - bounds[s]);
+    start_host[s] = (int)total;
+    const long long len = bounds[s + 1] - bounds[s];
+    total += (len + T - 1) / T * T;
+    if (total >= (1LL << 31)) return hipErrorInvalidValue;
+  }
+  pad_before[S] = (int)(total - bounds[S]);
+  start_host[S] = (int)total;
+  for (int s = S + 1; s < 9; ++s) start_host[s] = (int)total;
+  int* d_pad = nullptr;
+  unsigned short* c16 = nullptr;
+  if ((e = hipMalloc((void**)&d_pad, sizeof(int) * 9)) != hipSuccess) return e;
+  if ((e = hipMalloc((void**)&c16, sizeof(unsigned short) * (size_t)(total > 0 ? total : 1))) != hipSuccess) {
+    (void)hipFree(d_pad);
+    return e;
+  }
+  e = hipMemcpyAsync(d_pad, pad_before, sizeof(int) * (S + 1), hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipMemsetAsync(c16, 0xFF, sizeof(unsigned short) * (size_t)total, st);   // markers everywhere
+  if (e == hipSuccess) {
+    const long long vm1 = (long long)S * m + 1;
+    col16_rowptr_kernel<<<(unsigned)((vm1 + 255) / 256), 256, 0, st>>>(vrowptr, m, S, d_pad, vrowptr16);
+    int nb = (int)(((long long)S * m + 3) / 4);
+    if (nb > 16384) nb = 16384;
+    col16_scatter_kernel<<<nb, 256, 0, st>>>(vrowptr, vcol, vrowptr16, m, S, w, c16);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  (void)hipFree(d_pad);
+  if (e != hipSuccess) { (void)hipFree(c16); return e; }
+  *col16_out = c16;
+  *nnz16_host = (int)total;
+  return hipSuccess;
+}
+
 // ---- do the values factor as u[r] * u[c]?  (the GCN normalisation D^-1/2 (A+I) D^-1/2: u = D^-1/2) ----
 // u[r] = sqrt(A[r, r]) from the stored diagonal (binary search in the column-sorted row)
 __global__ void rank1_diag_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,

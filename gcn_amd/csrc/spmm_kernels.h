@@ -29,6 +29,8 @@ struct SpmmArgs {
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
   int tile_cols = 0;       // feature-column tile per pass: 0 auto, else 64 / 128 / 256
   int accumulate = 0;      // 1: C += A*B (C already holds another part of the product); epilogue after the add
+  int col16 = 0;           // 1 (value-free pass only): a.col is a 16-bit stream of offsets inside the slice, see spmm_quad.hip
+  int col16_S = 0, col16_w = 0, col16_start[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   int valless = 0;         // 1: ignore val (every entry counts 1): the caller pre-scaled B and post-scales the rows
   int gather_width = 0;    // 64-column tile: non-zeros per gather instruction, 0 auto (4 when eligible), 1, 4
   int blocks_per_cu = 32;  // grid size in 256-thread blocks per CU (1..64).  Up to 8 (4 for the 108-VGPR
@@ -83,6 +85,11 @@ hipError_t device_csr_apply_rank(const int* rowptr, const int* col, const float*
                                  int* bad_rank_host, hipStream_t st);
 
 // slicing.hip
+// 16-bit column stream of a sliced CSR (S <= 8, slice width <= 65 535): every slice padded to a multiple of T
+// with 0xFFFF markers; vrowptr16 [S*m+1] (the last row of a slice owns its markers), col16 [*nnz16_host],
+// start_host[S+1] = where each slice starts in the padded stream.  col16 is allocated here (caller frees).
+hipError_t build_col16_stream(const int* vrowptr, const int* vcol, int m, int n, int S, int T, int* vrowptr16,
+                              unsigned short** col16_out, int* nnz16_host, int* start_host, hipStream_t st);
 hipError_t build_sliced_csr(const int* rowptr, const int* col, const float* val, int m, int n,
                             int nnz, int S, int* vrowptr, int* vcol, float* vval,
                             int* sorted_out, hipStream_t st);

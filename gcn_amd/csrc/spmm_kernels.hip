@@ -473,7 +473,8 @@ void describe_main_kernel(const SpmmArgs& a, char* buf, size_t len) {
   const bool buf32 = (unsigned long long)a.n * (unsigned long long)(a.ldb > 0 ? a.ldb : a.k) * 4ull < 0xFFFFFFF0ull;
   if (a.nchunks_grid == 0) { snprintf(buf, len, "gcn::spmm_empty_kernel"); return; }
   if (use_quad(a)) {
-    snprintf(buf, len, "gcn::spmm_quad_kernel<%d, %s, %s>", spmm_quad_lanes(a.k), e, a.valless ? "true" : "false");
+    snprintf(buf, len, "gcn::spmm_quad_kernel<%d, %s, %s, %s>", spmm_quad_lanes(a.k), e, a.valless ? "true" : "false",
+             a.col16 ? "true" : "false");
     return;
   }
   if (a.k <= 16 && narrow_on && (a.ldb == 0 || a.ldb == a.k)) {

@@ -68,14 +68,23 @@ __device__ __forceinline__ float4 quad_reduce(float4 t) {
 // values factor as u[r]*u[c] (the GCN normalisation D^-1/2 (A+I) D^-1/2) the caller pre-scales B's rows by
 // u and scales the finished rows by u[r] (api.cpp, slice_reduce_kernel): the 4-byte value stream is
 // 5 % of what the sliced kernel moves across the fabric, and fabric bytes are its time.
-template <int LPE, bool EPI, bool VALLESS>
+// COL16 (value-free pass only): the column stream is 16 bits per non-zero — the column's offset inside its
+// slice (slices <= 65 535 columns wide).  The slice-major stream is laid out so that no chunk straddles two
+// slices (every slice padded to a multiple of the chunk size with 0xFFFF markers, which gather the all-zero
+// row n of the scaled copy of B), so the slice base is one scalar per chunk (QuadSlices: where each slice
+// starts in the padded stream, its width).  Saves 2 of the 4 index bytes per non-zero of the fabric traffic.
+struct QuadSlices { int S, w, start[9]; };           // start[s] .. start[s+1]: padded stream range of slice s (S <= 8)
+
+template <int LPE, bool EPI, bool VALLESS, bool COL16>
 __global__ void __launch_bounds__(256)
 spmm_quad_kernel(const int* __restrict__ g_rowptr, const int* __restrict__ g_col,
                  const float* __restrict__ g_val, const float* __restrict__ g_B,
                  float* __restrict__ g_C, float* __restrict__ g_P,
                  const int* __restrict__ g_chunk_row, const float* __restrict__ g_bias,
                  const int* __restrict__ nnz_dev,
-                 int relu, int nchunks, int T, int m, int nnz, int k, int col_tile, int accumulate, int ldb) {
+                 int relu, int nchunks, int T, int m, int nnz, int k, int col_tile, int accumulate, int ldb,
+                 QuadSlices sl, int n_rows_b) {
+  static_assert(!COL16 || VALLESS, "16-bit columns are only built for the value-free pass");
   if (nnz_dev) {                                    // drop-in (flexspmm) mode, see spmm_kernels.hip
     nnz = *nnz_dev;
     nchunks = (int)(((long long)nnz + T - 1) / T);
@@ -155,13 +164,26 @@ spmm_quad_kernel(const int* __restrict__ g_rowptr, const int* __restrict__ g_col
 
     int   cj_nx = 0;
     float vj_nx = 0.f;
-    if (start + tl < end) { cj_nx = a.col[start + tl]; if (!VALLESS) vj_nx = a.val[start + tl]; }
+    // 16-bit columns: this chunk's slice (chunks never straddle slices) -> its first column
+    int col_base = 0;
+    if (COL16) {
+#pragma unroll
+      for (int i = 1; i < 8; ++i) col_base += (i < sl.S && start >= sl.start[i]) ? sl.w : 0;
+    }
+    auto load_col = [&](int idx) -> int {
+      if (COL16) {
+        const int c16 = reinterpret_cast<const unsigned short*>(a.col)[idx];
+        return c16 == 0xFFFF ? n_rows_b : col_base + c16;          // marker -> the all-zero row behind B'
+      }
+      return a.col[idx];
+    };
+    if (start + tl < end) { cj_nx = load_col(start + tl); if (!VALLESS) vj_nx = a.val[start + tl]; }
     for (int base = start; base < end; base += 64) {
       const int cnt = min(64, end - base);
       const int cj = cj_nx;
       const int vj = __builtin_bit_cast(int, vj_nx);
       cj_nx = 0; vj_nx = 0.f;
-      if (base + 64 + tl < end) { cj_nx = a.col[base + 64 + tl]; if (!VALLESS) vj_nx = a.val[base + 64 + tl]; }
+      if (base + 64 + tl < end) { cj_nx = load_col(base + 64 + tl); if (!VALLESS) vj_nx = a.val[base + 64 + tl]; }
 
       float4 b[LPE];
 #define GCN_Q_GATHER(UU)                                                                         \
@@ -231,18 +253,24 @@ bool spmm_quad_eligible(const SpmmArgs& a) {
 template <int LPE>
 static hipError_t launch_quad(const SpmmArgs& a, int nblocks, bool epi, hipStream_t s) {
   const int tiles = (a.k + 4 * LPE - 1) / (4 * LPE);
+  QuadSlices sl{};
+  if (a.col16) {
+    sl.S = a.col16_S; sl.w = a.col16_w;
+    for (int i = 0; i < 9; ++i) sl.start[i] = a.col16_start[i];
+  }
   for (int t = 0; t < tiles; ++t) {
 #define GCN_QUAD_ARGS a.rowptr, a.col, a.val, a.B, a.C, a.P, a.chunk_row, a.bias, a.nnz_dev, \
-                      a.relu, a.nchunks, a.T, a.m, a.nnz, a.k, t, a.accumulate, (a.ldb > 0 ? a.ldb : a.k)
+                      a.relu, a.nchunks, a.T, a.m, a.nnz, a.k, t, a.accumulate, (a.ldb > 0 ? a.ldb : a.k), sl, a.n
     if constexpr (LPE == 16) {
-      if (a.valless && !epi) {                       // (the value-free variant is only built for the sliced main pass)
-        spmm_quad_kernel<LPE, false, true><<<dim3(nblocks), dim3(256), 0, s>>>(GCN_QUAD_ARGS);
+      if (a.valless && !epi) {                       // (the value-free variants are only built for the sliced main pass)
+        if (a.col16) spmm_quad_kernel<LPE, false, true, true><<<dim3(nblocks), dim3(256), 0, s>>>(GCN_QUAD_ARGS);
+        else         spmm_quad_kernel<LPE, false, true, false><<<dim3(nblocks), dim3(256), 0, s>>>(GCN_QUAD_ARGS);
         continue;
       }
     }
-    if (a.valless) return hipErrorInvalidValue;      // a caller bug: B was pre-scaled for a kernel that is not there
-    if (epi) spmm_quad_kernel<LPE, true, false><<<dim3(nblocks), dim3(256), 0, s>>>(GCN_QUAD_ARGS);
-    else     spmm_quad_kernel<LPE, false, false><<<dim3(nblocks), dim3(256), 0, s>>>(GCN_QUAD_ARGS);
+    if (a.valless || a.col16) return hipErrorInvalidValue;   // a caller bug: B was prepared for a kernel that is not there
+    if (epi) spmm_quad_kernel<LPE, true, false, false><<<dim3(nblocks), dim3(256), 0, s>>>(GCN_QUAD_ARGS);
+    else     spmm_quad_kernel<LPE, false, false, false><<<dim3(nblocks), dim3(256), 0, s>>>(GCN_QUAD_ARGS);
 #undef GCN_QUAD_ARGS
   }
   return hipGetLastError();

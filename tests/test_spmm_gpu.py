@@ -164,15 +164,15 @@ def test_main_kernel_families_are_selected_as_documented():
     assert adj.main_kernel(4).startswith("gcn::spmm_narrow_kernel<4,")
     assert adj.main_kernel(8).startswith("gcn::spmm_narrow_kernel<8,")
     assert adj.main_kernel(15) == "gcn::spmm_narrow16_dpp_kernel<false>"
-    assert adj.main_kernel(16) == "gcn::spmm_quad_kernel<4, false, false>"          # 16 non-zeros per gather
-    assert adj.main_kernel(17) == "gcn::spmm_quad_kernel<16, false, false>"         # odd widths run at k rounded up to 4
-    assert adj.main_kernel(32) == "gcn::spmm_quad_kernel<16, false, false>"         # 4 per gather, half the lanes idle
-    assert adj.main_kernel(128) == "gcn::spmm_quad_kernel<16, false, false>"        # 4 per gather
-    assert adj.main_kernel(128, epilogue=True) == "gcn::spmm_quad_kernel<16, true, false>"
+    assert adj.main_kernel(16) == "gcn::spmm_quad_kernel<4, false, false, false>"          # 16 non-zeros per gather
+    assert adj.main_kernel(17) == "gcn::spmm_quad_kernel<16, false, false, false>"         # odd widths run at k rounded up to 4
+    assert adj.main_kernel(32) == "gcn::spmm_quad_kernel<16, false, false, false>"         # 4 per gather, half the lanes idle
+    assert adj.main_kernel(128) == "gcn::spmm_quad_kernel<16, false, false, false>"        # 4 per gather
+    assert adj.main_kernel(128, epilogue=True) == "gcn::spmm_quad_kernel<16, true, false, false>"
     adj.set_gather_width(1)
     assert adj.main_kernel(16) == "gcn::spmm_narrow16_dpp_kernel<false>"
     adj.set_gather_width(0)
-    assert adj.main_kernel(130) == "gcn::spmm_quad_kernel<16, false, false>"        # k' = 132
+    assert adj.main_kernel(130) == "gcn::spmm_quad_kernel<16, false, false, false>"        # k' = 132
     adj.set_gather_width(1)
     assert adj.main_kernel(130).startswith("gcn::spmm_chunk_kernel<1,")      # one non-zero per gather, caller's layout
     assert adj.main_kernel(128).startswith("gcn::spmm_chunk_kernel<1,")
@@ -184,7 +184,7 @@ def test_main_kernel_families_are_selected_as_documented():
     assert short.main_kernel(16) == "gcn::spmm_narrow16_dpp_kernel<false>"
     assert short.main_kernel(130).startswith("gcn::spmm_chunk_kernel<1,")    # and no detour over k' = 132
     short.set_gather_width(4)
-    assert short.main_kernel(128) == "gcn::spmm_quad_kernel<16, false, false>"
+    assert short.main_kernel(128) == "gcn::spmm_quad_kernel<16, false, false, false>"
     adj.set_tile_cols(256)
     assert adj.main_kernel(256).startswith("gcn::spmm_chunk_kernel<4,")
     adj.set_tile_cols(128)
@@ -639,7 +639,7 @@ def test_value_free_sliced_pass_for_normalised_adjacencies():
         B = rng.standard_normal((n, k)).astype(np.float32)
         bias = rng.standard_normal(k).astype(np.float32)
         adj = _adj(rowptr, col, val, n, n)
-        assert adj.num_slices >= 2 and adj.main_kernel(k) == "gcn::spmm_quad_kernel<16, false, true>"
+        assert adj.num_slices >= 2 and adj.main_kernel(k) == "gcn::spmm_quad_kernel<16, false, true, true>"
         Bd = torch.from_numpy(B).to(_dev())
         Cref = oracle_spmm(rowptr, col, val, B)
         assert rel_err(adj.matmul_raw(Bd).cpu().numpy(), Cref) <= TOL
@@ -649,13 +649,13 @@ def test_value_free_sliced_pass_for_normalised_adjacencies():
     # one entry off by 1e-4 relative: no longer rank-1 -> the ordinary kernel, and the right answer
     val2 = val.copy(); val2[len(val2) // 2] *= 1.0001
     adj2 = _adj(rowptr, col, val2, n, n)
-    assert adj2.num_slices >= 2 and adj2.main_kernel(128) == "gcn::spmm_quad_kernel<16, false, false>"
+    assert adj2.num_slices >= 2 and adj2.main_kernel(128) == "gcn::spmm_quad_kernel<16, false, false, false>"
     B = rng.standard_normal((n, 128)).astype(np.float32)
     assert rel_err(adj2.matmul_raw(torch.from_numpy(B).to(_dev())).cpu().numpy(), oracle_spmm(rowptr, col, val2, B)) <= TOL
     # arbitrary weights
     val3 = (rng.random(len(val)) + 0.1).astype(np.float32)
     adj3 = _adj(rowptr, col, val3, n, n)
-    assert adj3.main_kernel(128) == "gcn::spmm_quad_kernel<16, false, false>"
+    assert adj3.main_kernel(128) == "gcn::spmm_quad_kernel<16, false, false, false>"
     assert rel_err(adj3.matmul_raw(torch.from_numpy(B).to(_dev())).cpu().numpy(), oracle_spmm(rowptr, col, val3, B)) <= TOL
 
 
@@ -674,12 +674,12 @@ def test_explicit_value_factors_on_a_row_block_with_renumbered_columns():
     rp, ci, va = Ablk.indptr.astype(np.int32), Ablk.indices.astype(np.int32), Ablk.data.astype(np.float32)
     adj = _adj(rp, ci, va, hi - lo, n, slices=2)                # 75 non-zeros per virtual row: the quad kernel
     assert not adj.has_value_factors                            # rectangular: nothing to detect
-    assert adj.main_kernel(128) == "gcn::spmm_quad_kernel<16, false, false>"
+    assert adj.main_kernel(128) == "gcn::spmm_quad_kernel<16, false, false, false>"
     B = np.random.default_rng(3).standard_normal((n, 128)).astype(np.float32)
     Bd = torch.from_numpy(B).to(_dev())
     plain = adj.matmul_raw(Bd).cpu().numpy()
     adj.set_value_factors(torch.from_numpy(u[lo:hi]), torch.from_numpy(u_col))
-    assert adj.has_value_factors and adj.main_kernel(128) == "gcn::spmm_quad_kernel<16, false, true>"
+    assert adj.has_value_factors and adj.main_kernel(128) == "gcn::spmm_quad_kernel<16, false, true, true>"
     fast = adj.matmul_raw(Bd).cpu().numpy()
     Cref = oracle_spmm(rp, ci, va, B)
     assert rel_err(plain, Cref) <= TOL and rel_err(fast, Cref) <= TOL
