@@ -646,6 +646,15 @@ def test_value_free_sliced_pass_for_normalised_adjacencies():
         Ce = adj.matmul_raw(Bd, bias=torch.from_numpy(bias).to(_dev()), relu=True).cpu().numpy()
         assert rel_err(Ce, np.maximum(Cref + bias, 0)) <= TOL
         assert torch.equal(adj.matmul_raw(Bd), adj.matmul_raw(Bd))          # reproducible
+    # every slice count the 16-bit stream supports (the four-per-gather kernel forced: 4 / 8 slices leave
+    # virtual rows shorter than the automatic rule wants), on a graph whose size is not a multiple of any of them
+    B = rng.standard_normal((n, 128)).astype(np.float32)
+    Cref = oracle_spmm(rowptr, col, val, B)
+    for S in (2, 3, 4, 7, 8):
+        adj = _adj(rowptr, col, val, n, n, slices=S)
+        adj.set_gather_width(4)
+        assert adj.num_slices == S and adj.main_kernel(128) == "gcn::spmm_quad_kernel<16, false, true, true>"
+        assert rel_err(adj.matmul_raw(torch.from_numpy(B).to(_dev())).cpu().numpy(), Cref) <= TOL
     # one entry off by 1e-4 relative: no longer rank-1 -> the ordinary kernel, and the right answer
     val2 = val.copy(); val2[len(val2) // 2] *= 1.0001
     adj2 = _adj(rowptr, col, val2, n, n)
