@@ -41,6 +41,11 @@ struct gcn_spmm_plan {
   int *vrowptr16, *vchunk_row16;  // 16-bit column stream of the sliced CSR (value-free pass): [S*m+1], [nchunks16]
   unsigned short* vcol16;       // [nnz16] offsets inside the slice, 0xFFFF = padding marker
   int nnz16, nchunks16, start16[9];
+  // 15-bit slice-major stream of the group kernel (spmm_group.hip), value-free pass
+  unsigned short* gstream;      // [gnchunks*gT]
+  int *gchunk_row, *gvrowptr;   // [gnchunks], [S*m+1]
+  int* gchunk_meta;             // int2 [gnchunks]
+  int gnchunks, gT, gw;
   float* u_row;                 // [m], [n]: factors of rank-1 values (val[r,c] = u_row[r]*u_col[c]); null when
   float* u_col;                 // the values do not factor (u_col == u_row for a square normalised adjacency)
   float* bpad;                  // B re-laid with rows padded to whole 128-byte lines (odd k), grow-only
@@ -118,6 +123,22 @@ static bool col16_enabled() {
   return v;
 }
 
+// the group kernel (spmm_group.hip) for the value-free sliced pass (development knobs: GCN_AMD_GROUP=0 off,
+// GCN_AMD_GROUP_T chunk size per 16-lane group, GCN_AMD_GROUP_SC1=0 plain instead of write-through partial-row stores)
+static bool group_enabled() {
+  static const bool v = [] { const char* e = std::getenv("GCN_AMD_GROUP"); return !e || e[0] != '0'; }();
+  return v;
+}
+static int group_chunk() {
+  static const int v = [] { const char* e = std::getenv("GCN_AMD_GROUP_T"); const int t = e ? std::atoi(e) : 512;
+                            return (t == 256 || t == 512 || t == 1024 || t == 2048) ? t : 512; }();
+  return v;
+}
+static bool group_sc1() {
+  static const bool v = [] { const char* e = std::getenv("GCN_AMD_GROUP_SC1"); return !e || e[0] != '0'; }();
+  return v;
+}
+
 // re-lay B with rows padded to whole cache lines for k % 32 != 0 (development knob GCN_AMD_PAD_B=0: off)
 static bool pad_b_enabled() {
   static const bool v = [] { const char* e = std::getenv("GCN_AMD_PAD_B"); return !e || e[0] != '0'; }();
@@ -169,6 +190,8 @@ static int slice_min_k() {
 static bool rows_long_enough_for_quad(const gcn_spmm_plan* p, int k) {
   if (p->gather_width == 4) return true;
   const bool sliced = p->S > 0 && k >= slice_min_k();
+  // (the group kernel of the value-free pass does not mind short rows)
+  if (sliced && p->gstream && p->u_row && p->panel_R == 0 && p->nnz / p->n >= 96) return true;
   const long long rows = sliced ? (long long)p->S * p->m : (long long)p->m;
   return rows > 0 && p->nnz / rows >= 48;
 }
@@ -185,6 +208,8 @@ static bool rows_long_enough_for_quad(const gcn_spmm_plan* p, int k) {
 // non-zeros per virtual row; at mean degree 51 (products-shaped) slicing loses and stays off.
 int auto_slices(long long m, long long n, long long nnz) {
   if (m <= 0 || nnz <= 0) return 0;
+  static const int forced = [] { const char* e = std::getenv("GCN_AMD_SLICES"); return e ? std::atoi(e) : -1; }();
+  if (forced >= 0) return forced;                     // development knob: the slice count "auto" resolves to
   if (nnz / m < 128) return 0;                        // low degree: partial rows outweigh the hits
   const long long table = n * 256;                    // bytes of one 64-column tile of B
   if (table <= (4LL << 20)) return 0;                 // fits every L2 as it is
@@ -289,6 +314,10 @@ int gcn_spmm_plan_destroy(gcn_spmm_plan_t* p) {
   if (p->vrowptr16) (void)hipFree(p->vrowptr16);
   if (p->vchunk_row16) (void)hipFree(p->vchunk_row16);
   if (p->vcol16) (void)hipFree(p->vcol16);
+  if (p->gstream) (void)hipFree(p->gstream);
+  if (p->gchunk_row) (void)hipFree(p->gchunk_row);
+  if (p->gchunk_meta) (void)hipFree(p->gchunk_meta);
+  if (p->gvrowptr) (void)hipFree(p->gvrowptr);
   free_factors(p);
   if (p->bpad) (void)hipFree(p->bpad);
   if (p->cpad) (void)hipFree(p->cpad);
@@ -308,6 +337,7 @@ size_t gcn_spmm_plan_workspace_bytes(const gcn_spmm_plan_t* p, int32_t k) {
   if (!p || k <= 0) return 0;
   int chunks = p->nchunks > p->pout_nchunks ? p->nchunks : p->pout_nchunks;
   if (p->nchunks16 > chunks) chunks = p->nchunks16;
+  if (p->gnchunks > chunks) chunks = p->gnchunks;
   return sizeof(float) * 2 * (size_t)(chunks > 0 ? chunks : 1) * (size_t)k;
 }
 
@@ -327,6 +357,7 @@ static int spmm_impl(gcn_spmm_plan_t* p, const int32_t* rowptr, const int32_t* c
                      const float* B, int b_ld, bool b_scaled, float* C, const float* bias, int32_t relu, int32_t k,
                      void* stream);
 static bool valless_pays(const gcn_spmm_plan_t* p, const gcn::SpmmArgs& base, int k, int ldb);
+static int relay_B(gcn_spmm_plan_t* p, const float* B, int k, int ldb, bool scaled, hipStream_t st);
 
 int gcn_spmm_csr_f32_bias_relu(gcn_spmm_plan_t* p, const int32_t* rowptr, const int32_t* col,
                                const float* val, const float* B, float* C, const float* bias,
@@ -343,13 +374,11 @@ int gcn_spmm_csr_f32_bias_relu(gcn_spmm_plan_t* p, const int32_t* rowptr, const 
       rows_long_enough_for_quad(p, k)) {
     const int kp = (k + 3) / 4 * 4, ldb = (kp + 31) / 32 * 32;
     if ((long long)sizeof(float) * p->n * ldb <= (768LL << 20)) {
-      int st = grow(p->bpad, p->bpad_bytes, sizeof(float) * ((size_t)p->n + 1) * (size_t)ldb);
-      if (st == GCN_OK) st = grow(p->cpad, p->cpad_bytes, sizeof(float) * (size_t)p->m * (size_t)kp);
+      int st = grow(p->cpad, p->cpad_bytes, sizeof(float) * (size_t)p->m * (size_t)kp);
       if (st != GCN_OK) return st;
       const bool scaled = valless_pays(p, gcn::SpmmArgs{}, kp, ldb);       // the copy can carry the u_col scaling
-      if (gcn::launch_pad_rows(p->bpad, B, p->n, k, ldb, (hipStream_t)stream, scaled ? p->u_col : nullptr) != hipSuccess ||
-          hipMemsetAsync(p->bpad + (size_t)p->n * ldb, 0, sizeof(float) * (size_t)ldb, (hipStream_t)stream) != hipSuccess)
-        return GCN_ERR_HIP;
+      st = relay_B(p, B, k, ldb, scaled, (hipStream_t)stream);
+      if (st != GCN_OK) return st;
       st = spmm_impl(p, rowptr, col, val, p->bpad, ldb, scaled, p->cpad, nullptr, 0, kp, stream);
       if (st != GCN_OK) return st;
       return gcn::launch_unpad_rows(C, p->cpad, bias, relu ? 1 : 0, p->m, k, kp, (hipStream_t)stream) == hipSuccess
@@ -366,12 +395,34 @@ static bool valless_pays(const gcn_spmm_plan_t* p, const gcn::SpmmArgs& base, in
   //  4 bytes per non-zero plus instructions — measured break-even near 65 non-zeros per column of the
   //  block: the rank-0 share of an 8-way partition of the Reddit-shaped graph (62 per column) does not gain)
   if (!sliced || !p->u_row || p->panel_R != 0 || p->nnz / p->n < 96) return false;
+  if (p->gstream && gcn::spmm_group_eligible(k, ldb, nullptr, nullptr, nullptr)) return true;   // spmm_group.hip
   gcn::SpmmArgs t = base;                              // the launch as the sliced branch will issue it
   t.B = nullptr; t.C = nullptr; t.bias = nullptr; t.relu = 0; t.k = k; t.nnz = p->nnz; t.n = p->n;
   t.nchunks_grid = p->nchunks; t.T = p->T; t.nnz_dev = nullptr;
   t.m = p->S * p->m; t.ldb = ldb; t.tile_cols = p->tile_cols ? p->tile_cols : 64;
   t.gather_width = p->gather_width;
   return gcn::spmm_will_use_quad(t) && gcn::spmm_quad_lanes(k) == 16;
+}
+
+// the value-free pass of this plan runs the group kernel (its scaled copy of B is then laid out slice by slice)
+static bool group_pass(const gcn_spmm_plan_t* p) { return p->gstream != nullptr; }
+
+// Copy of B the sliced main pass gathers from: rows `ldb` floats apart (>= k, padding columns zero), scaled by
+// u_col when `scaled`; one all-zero row more than B has (16-bit stream) or, for the group kernel, slice s at
+// rows [s*(w+1), (s+1)*(w+1)) with row w of every slice zero.
+static int relay_B(gcn_spmm_plan_t* p, const float* B, int k, int ldb, bool scaled, hipStream_t st) {
+  if (scaled && group_pass(p)) {
+    const size_t rows = (size_t)p->S * (size_t)(p->gw + 1);
+    const int rc = grow(p->bpad, p->bpad_bytes, sizeof(float) * rows * (size_t)ldb);
+    if (rc != GCN_OK) return rc;
+    return gcn::launch_scale_rows_sliced(p->bpad, B, p->u_col, p->n, k, ldb, p->S, p->gw, st) == hipSuccess ? GCN_OK : GCN_ERR_HIP;
+  }
+  const int rc = grow(p->bpad, p->bpad_bytes, sizeof(float) * ((size_t)p->n + 1) * (size_t)ldb);
+  if (rc != GCN_OK) return rc;
+  if (gcn::launch_pad_rows(p->bpad, B, p->n, k, ldb, st, scaled ? p->u_col : nullptr) != hipSuccess ||
+      hipMemsetAsync(p->bpad + (size_t)p->n * ldb, 0, sizeof(float) * (size_t)ldb, st) != hipSuccess)
+    return GCN_ERR_HIP;
+  return GCN_OK;
 }
 
 static int spmm_impl(gcn_spmm_plan_t* p, const int32_t* rowptr, const int32_t* col, const float* val,
@@ -404,12 +455,8 @@ static int spmm_impl(gcn_spmm_plan_t* p, const int32_t* rowptr, const int32_t* c
     const int ldb = padded_ldb(p->n, k);
     valless = valless_pays(p, a, k, ldb);
     if (ldb != k || valless) {
-      // (one row more than B has: the all-zero row the 16-bit stream's padding markers gather)
-      const int st = grow(p->bpad, p->bpad_bytes, sizeof(float) * ((size_t)p->n + 1) * (size_t)ldb);
+      const int st = relay_B(p, B, k, ldb, valless, (hipStream_t)stream);
       if (st != GCN_OK) return st;
-      if (gcn::launch_pad_rows(p->bpad, B, p->n, k, ldb, (hipStream_t)stream, valless ? p->u_col : nullptr) != hipSuccess ||
-          hipMemsetAsync(p->bpad + (size_t)p->n * ldb, 0, sizeof(float) * (size_t)ldb, (hipStream_t)stream) != hipSuccess)
-        return GCN_ERR_HIP;
       a.B = p->bpad;
       a.ldb = ldb;
     }
@@ -479,6 +526,22 @@ static int spmm_impl(gcn_spmm_plan_t* p, const int32_t* rowptr, const int32_t* c
     a.rowptr = p->vrowptr; a.col = p->vcol; a.val = p->vval; a.chunk_row = p->vchunk_row;
     a.C = p->cv; a.m = p->S * p->m; a.bias = nullptr; a.relu = 0;
     const float* rowscale = nullptr;
+    if (valless && group_pass(p)) {
+      // four independent 16-lane row engines per wave on the 15-bit slice-major stream (spmm_group.hip)
+      gcn::GroupArgs ga;
+      ga.stream = p->gstream; ga.chunk_meta = p->gchunk_meta;
+      ga.Bp = a.B; ga.Cv = p->cv; ga.P = p->ws;
+      ga.nchunks = p->gnchunks; ga.T = p->gT; ga.k = k; ga.ldb = a.ldb;
+      ga.write_through = group_sc1() ? 1 : 0;
+      hipStream_t st = (hipStream_t)stream;
+      if (a.ev_start && hipEventRecord(a.ev_start, st) != hipSuccess) return GCN_ERR_HIP;
+      if (gcn::launch_spmm_group(ga, st) != hipSuccess) return GCN_ERR_HIP;
+      if (a.ev_stop && hipEventRecord(a.ev_stop, st) != hipSuccess) return GCN_ERR_HIP;
+      if (gcn::launch_spmm_fixup(p->gvrowptr, p->ws, p->cv, p->gchunk_row, p->gnchunks, p->gT, k, st) != hipSuccess)
+        return GCN_ERR_HIP;
+      return gcn::launch_slice_reduce(p->cv, C, bias, relu ? 1 : 0, p->m, p->S, k, st, 0, p->u_row) == hipSuccess
+                 ? GCN_OK : GCN_ERR_HIP;
+    }
     if (valless) {                                                          // B was scaled by u_col above
       a.valless = 1; a.val = nullptr; rowscale = p->u_row;
       if (p->vcol16) {                                                      // 16-bit column stream, slice-aligned chunks
@@ -504,6 +567,11 @@ static void free_slicing(gcn_spmm_plan* p) {
   if (p->vrowptr16) (void)hipFree(p->vrowptr16);
   if (p->vchunk_row16) (void)hipFree(p->vchunk_row16);
   if (p->vcol16) (void)hipFree(p->vcol16);
+  if (p->gstream) (void)hipFree(p->gstream);
+  if (p->gchunk_row) (void)hipFree(p->gchunk_row);
+  if (p->gchunk_meta) (void)hipFree(p->gchunk_meta);
+  if (p->gvrowptr) (void)hipFree(p->gvrowptr);
+  p->gstream = nullptr; p->gchunk_row = p->gvrowptr = p->gchunk_meta = nullptr; p->gnchunks = p->gT = p->gw = 0;
   p->vrowptr16 = p->vchunk_row16 = nullptr; p->vcol16 = nullptr; p->nnz16 = p->nchunks16 = 0;
   p->vrowptr = p->vcol = p->vchunk_row = nullptr; p->vval = nullptr; p->cv = nullptr;
   p->cv_bytes = 0; p->S = 0;
@@ -542,9 +610,21 @@ int gcn_spmm_plan_enable_slicing(gcn_spmm_plan_t* p, const int32_t* rowptr, cons
     return GCN_ERR_HIP;
   }
   p->S = slices;
+  // 15-bit stream of the group kernel (value-free pass): slices at most 32 767 columns wide; best effort
+  if ((p->n + slices - 1) / slices <= 32767 && group_enabled()) {
+    if (hipMalloc((void**)&p->gvrowptr, sizeof(int) * (size_t)(vm + 1)) == hipSuccess) {
+      int nch = 0;
+      if (gcn::build_group_stream(p->vrowptr, p->vcol, p->m, p->n, slices, group_chunk(), p->gvrowptr, &p->gstream,
+                                  &p->gchunk_row, &p->gchunk_meta, &nch, (hipStream_t)stream) == hipSuccess && nch > 0) {
+        p->gnchunks = nch; p->gT = group_chunk(); p->gw = (p->n + slices - 1) / slices;
+      } else {
+        (void)hipFree(p->gvrowptr); p->gvrowptr = nullptr;
+      }
+    }
+  }
   // 16-bit column stream for the value-free pass (2 instead of 4 index bytes per non-zero across the fabric):
   // slices at most 65 535 columns wide, at most 8 of them; best effort — without it the 32-bit stream is used
-  if (slices <= 8 && (p->n + slices - 1) / slices <= 65535 && col16_enabled()) {
+  if (!p->gstream && slices <= 8 && (p->n + slices - 1) / slices <= 65535 && col16_enabled()) {
     if (hipMalloc((void**)&p->vrowptr16, sizeof(int) * (size_t)(vm + 1)) == hipSuccess) {
       int nnz16 = 0;
       if (gcn::build_col16_stream(p->vrowptr, p->vcol, p->m, p->n, slices, p->T, p->vrowptr16, &p->vcol16, &nnz16,
@@ -743,6 +823,10 @@ int gcn_spmm_plan_main_kernel(const gcn_spmm_plan_t* p, int32_t k, int32_t epilo
     if (const int ldb = padded_ldb(p->n, k); ldb != k) a.ldb = ldb;
     a.valless = valless_pays(p, a, k, a.ldb > 0 ? a.ldb : k);   // as spmm_impl decides
     a.col16 = a.valless && p->vcol16 != nullptr;
+  }
+  if (a.valless && group_pass(p)) {
+    snprintf(buf, (size_t)buflen, "gcn::spmm_group_kernel<%d, %s>", p->gT, group_sc1() ? "true" : "false");
+    return GCN_OK;
   }
   gcn::describe_main_kernel(a, buf, (size_t)buflen);
   return GCN_OK;

@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 #include <stdint.h>
+#include <vector>
 #include "spmm_kernels.h"
 
 namespace gcn {
@@ -266,6 +267,149 @@ hipError_t build_col16_stream(const int* vrowptr, const int* vcol, int m, int n,
   *col16_out = c16;
   *nnz16_host = (int)total;
   return hipSuccess;
+}
+
+// ---- 15-bit slice-major stream of the group kernel (spmm_group.hip) ----
+// len[vr] = max(1, entries of virtual row vr): empty virtual rows get one padding entry
+__global__ void group_len_kernel(const int* __restrict__ vrowptr, long long vm, int* __restrict__ len) {
+  const long long vr = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (vr > vm) return;
+  const int l = vr < vm ? vrowptr[vr + 1] - vrowptr[vr] : 0;
+  len[vr] = vr < vm ? (l > 0 ? l : 1) : 0;
+}
+
+// pos[vr] (exclusive scan of len) -> position in the padded stream; pos[vm] -> total
+__global__ void group_rowptr_kernel(const int* __restrict__ pos, int m, int S, const int* __restrict__ pad_before,
+                                    int* __restrict__ vrowptr_g) {
+  const long long vr = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (vr > (long long)S * m) return;
+  vrowptr_g[vr] = pos[vr] + pad_before[(int)(vr / m)];       // vr == S*m -> pad_before[S] = all the padding
+}
+
+// one wave per virtual row: entries = column offset inside the slice; the LAST stream position the row owns
+// (which for the last row of a slice is the end of the slice's padding) carries the row-end bit
+__global__ void __launch_bounds__(256)
+group_scatter_kernel(const int* __restrict__ vrowptr, const int* __restrict__ vcol, const int* __restrict__ vrowptr_g,
+                     int m, int S, int w, unsigned short* __restrict__ stream) {
+  const int lane = threadIdx.x & 63;
+  const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long long nw = (long long)gridDim.x * 4;
+  for (long long vr = wave; vr < (long long)S * m; vr += nw) {
+    const int base = (int)(vr / m) * w;
+    const int src = vrowptr[vr], len = vrowptr[vr + 1] - src;
+    const int dst = vrowptr_g[vr], last = vrowptr_g[vr + 1] - 1;
+    for (int i = lane; i < len; i += 64)
+      stream[dst + i] = (unsigned short)((vcol[src + i] - base) | (dst + i == last ? 0x8000 : 0));
+    if (lane == 0 && last >= dst + len) stream[last] = (unsigned short)(w | 0x8000);   // padding entry ends the row
+  }
+}
+
+// meta[c] = {2 * chunk_row[c] + (the row began before the chunk), first row of the chunk's slice in B'}
+__global__ void group_meta_kernel(const int* __restrict__ chunk_row, const int* __restrict__ vrowptr_g, int nchunks,
+                                  int T, int m, int w, int2* __restrict__ meta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nchunks) return;
+  const int vr = chunk_row[c];
+  meta[c] = make_int2(2 * vr + (vrowptr_g[vr] < (long long)c * T ? 1 : 0), (vr / m) * (w + 1));
+}
+
+hipError_t build_group_stream(const int* vrowptr, const int* vcol, int m, int n, int S, int T, int* vrowptr_g,
+                              unsigned short** stream_out, int** chunk_row_out, int** chunk_meta_out,
+                              int* nchunks_host, hipStream_t st) {
+  *stream_out = nullptr; *chunk_row_out = nullptr; *chunk_meta_out = nullptr; *nchunks_host = 0;
+  const int w = (n + S - 1) / S;
+  if (S < 1 || S > 256 || w > 32767 || m <= 0 || T < 16 || T % 16) return hipErrorInvalidValue;
+  const long long vm = (long long)S * m;
+  int *len = nullptr, *pos = nullptr, *d_pad = nullptr, *chunk_row = nullptr;
+  int2* meta = nullptr;
+  unsigned short* stream = nullptr;
+  void* tmp = nullptr;
+  size_t tmp_bytes = 0;
+  hipError_t err = hipSuccess;
+  auto cleanup = [&](bool all) {
+    if (len) (void)hipFree(len);
+    if (pos) (void)hipFree(pos);
+    if (d_pad) (void)hipFree(d_pad);
+    if (tmp) (void)hipFree(tmp);
+    if (all) { if (stream) (void)hipFree(stream); if (chunk_row) (void)hipFree(chunk_row); if (meta) (void)hipFree(meta); }
+  };
+#define GCN_GO(x) do { err = (x); if (err != hipSuccess) { cleanup(true); return err; } } while (0)
+  GCN_GO(hipMalloc((void**)&len, sizeof(int) * (size_t)(vm + 1)));
+  GCN_GO(hipMalloc((void**)&pos, sizeof(int) * (size_t)(vm + 1)));
+  GCN_GO(hipMalloc((void**)&d_pad, sizeof(int) * (size_t)(S + 1)));
+  group_len_kernel<<<(unsigned)((vm + 256) / 256), 256, 0, st>>>(vrowptr, vm, len);
+  GCN_GO(hipGetLastError());
+  GCN_GO(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, len, pos, (int)(vm + 1), st));
+  GCN_GO(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
+  GCN_GO(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, len, pos, (int)(vm + 1), st));
+  // slice boundaries of the unpadded stream -> where each slice starts once padded to whole chunks
+  std::vector<int> bounds(S + 1), pad_before(S + 1);
+  for (int s = 0; s <= S; ++s)
+    GCN_GO(hipMemcpyAsync(&bounds[s], pos + (size_t)s * m, sizeof(int), hipMemcpyDeviceToHost, st));
+  GCN_GO(hipStreamSynchronize(st));
+  long long total = 0;
+  for (int s = 0; s < S; ++s) {
+    pad_before[s] = (int)(total - bounds[s]);
+    const long long l = bounds[s + 1] - bounds[s];
+    total += (l + T - 1) / T * T;
+  }
+  total = (total + 32LL * T - 1) / (32LL * T) * (32LL * T);     // whole waves for every XCD (spmm_group_kernel)
+  if (total >= (1LL << 31)) { cleanup(true); return hipErrorInvalidValue; }
+  pad_before[S] = (int)(total - bounds[S]);
+  const int nchunks = (int)(total / T);
+  GCN_GO(hipMalloc((void**)&stream, sizeof(unsigned short) * (size_t)total));
+  GCN_GO(hipMalloc((void**)&chunk_row, sizeof(int) * (size_t)nchunks));
+  GCN_GO(hipMemcpyAsync(d_pad, pad_before.data(), sizeof(int) * (size_t)(S + 1), hipMemcpyHostToDevice, st));
+  GCN_GO(hipMemsetD16Async((hipDeviceptr_t)stream, (unsigned short)w, (size_t)total, st));   // zero-row entries everywhere
+  group_rowptr_kernel<<<(unsigned)((vm + 256) / 256), 256, 0, st>>>(pos, m, S, d_pad, vrowptr_g);
+  {
+    int nb = (int)((vm + 3) / 4);
+    if (nb > 16384) nb = 16384;
+    group_scatter_kernel<<<nb, 256, 0, st>>>(vrowptr, vcol, vrowptr_g, m, S, w, stream);
+  }
+  GCN_GO(hipGetLastError());
+  GCN_GO(launch_plan_chunk_rows(vrowptr_g, (int)vm, T, nchunks, chunk_row, st));
+  GCN_GO(hipMalloc((void**)&meta, sizeof(int2) * (size_t)nchunks));
+  group_meta_kernel<<<(nchunks + 255) / 256, 256, 0, st>>>(chunk_row, vrowptr_g, nchunks, T, m, w, meta);
+  GCN_GO(hipGetLastError());
+  GCN_GO(hipStreamSynchronize(st));                              // (pad_before is a host buffer)
+#undef GCN_GO
+  cleanup(false);
+  *stream_out = stream; *chunk_row_out = chunk_row; *chunk_meta_out = reinterpret_cast<int*>(meta); *nchunks_host = nchunks;
+  return hipSuccess;
+}
+
+// scaled copy of B in the group kernel's layout: slice s at rows [s*(w+1), (s+1)*(w+1)), the last one zero
+__global__ void __launch_bounds__(256)
+scale_rows_sliced_kernel(float* __restrict__ dst, const float* __restrict__ src, const float* __restrict__ rowscale,
+                         int n, int k, int ld, int S, int w) {
+  const int ld4 = ld >> 2;                                       // float4 per destination row
+  const long long total = (long long)S * (w + 1) * ld4;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const long long R = i / ld4;
+    const int x = (int)(i - R * ld4) * 4;
+    const int s = (int)(R / (w + 1)), j = (int)(R - (long long)s * (w + 1));
+    const long long c = (long long)s * w + j;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (j < w && c < n && x < k) {
+      const float u = rowscale[c];
+      const float* p = src + c * k + x;
+      if ((k & 3) == 0) { const float4 t = *reinterpret_cast<const float4*>(p); v = make_float4(u * t.x, u * t.y, u * t.z, u * t.w); }
+      else { v.x = u * p[0]; if (x + 1 < k) v.y = u * p[1]; if (x + 2 < k) v.z = u * p[2]; if (x + 3 < k) v.w = u * p[3]; }
+    }
+    *reinterpret_cast<float4*>(dst + R * ld + x) = v;
+  }
+}
+
+hipError_t launch_scale_rows_sliced(float* dst, const float* src, const float* rowscale, int n, int k, int ld,
+                                    int S, int w, hipStream_t s) {
+  if (n <= 0 || k <= 0) return hipSuccess;
+  if (ld % 4 != 0 || ((uintptr_t)dst & 15) != 0 || ((k & 3) == 0 && ((uintptr_t)src & 15) != 0)) return hipErrorInvalidValue;
+  long long nb = ((long long)S * (w + 1) * (ld / 4) + 255) / 256;
+  if (nb > 65536) nb = 65536;
+  scale_rows_sliced_kernel<<<(int)nb, 256, 0, s>>>(dst, src, rowscale, n, k, ld, S, w);
+  return hipGetLastError();
 }
 
 // ---- do the values factor as u[r] * u[c]?  (the GCN normalisation D^-1/2 (A+I) D^-1/2: u = D^-1/2) ----

@@ -1,0 +1,172 @@
+// spmm_group.hip — the sliced main pass as FOUR independent 16-lane row engines per wave.
+//
+// Why (profiles/r02c_pmc_main_kernel.txt, Reddit-shaped k = 128, 8 slices): the four-per-gather kernel
+// of spmm_quad.hip keeps one row per WAVE — its four 16-lane groups hold four interleaved partial sums of
+// the same row — so every row end costs a cross-lane reduction, a scalar walk over the 64-entry block with
+// per-lane masks, and scalar row-pointer loads.  With 8 column slices a virtual row is 62 entries long, so
+// nearly every 64-entry block takes that slow path: 236 scalar and 189 vector instructions per block
+// against 17 vector-memory instructions, the texture addresser busy 58 % of the time, and every further
+// slice (shorter virtual rows) made it slower although the L2 misses halved.
+//
+// Here each 16-lane group (lane = g*16 + f, f = which float4 of the 64-column tile) walks its OWN chunk
+// of the slice-major stream, one entry per step, and owns the complete sum of its current row:
+//   * one global_load_dwordx4 still fetches four feature rows (4 x 256 B), one per group;
+//   * a row end is a bit in the stream (bit 15 of the 16-bit entry) and costs the group ONE 256-byte store
+//     under an EXEC mask — no cross-lane traffic, no row pointers in the kernel at all;
+//   * entries are 16 bits: the column's offset inside its slice (slices <= 32 767 columns); every virtual
+//     row has at least one entry (empty ones get a padding entry that gathers the slice's all-zero row),
+//     so "next row" is pointer arithmetic;
+//   * the byte offset of the gathered row is computed once per entry at load time (one lane = one entry
+//     of its group's 16-entry block) and reaches the group by a DPP row broadcast fused into the address
+//     add: per step one VALU op for the address, one load, two packed adds.
+// Chunks are T entries of ONE group; a wave owns four consecutive chunks, a block sixteen, and the blocks
+// of an XCD take consecutive chunks in dispatch order, so an XCD walks its part of the stream front to
+// back and slices meet its L2 one after the other (with more chunks per wave, as before, the second
+// chunk of an early wave ran beside the first chunk of a late one: two slices in one L2).
+// Row pieces that cross chunk ends go to the partial slab P and are added by spmm_fixup_kernel in chunk
+// order, as everywhere else: results are bitwise reproducible.
+//
+// Value-free only (every stored entry counts 1): the caller gathers from a copy of B whose rows were
+// scaled by u_col and scales finished rows by u_row (api.cpp); matrices whose values do not factor keep
+// the four-per-gather kernel.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include "spmm_kernels.h"
+
+namespace gcn {
+
+// value held by lane UU of this lane's 16-lane row (DPP row_newbcast)
+template <int UU>
+__device__ __forceinline__ int row_bcast(int v) {
+  return __builtin_amdgcn_mov_dpp(v, 0x150 + UU, 0xf, 0xf, true);
+}
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Partial-row store.  WT: write-through (sc1) — the line is dropped from the XCD's L2 instead of staying
+// there: the slab is read back only by the reduction that follows, and left in L2 its lines push out
+// feature rows the gathers are about to reuse (MI355X_MICROARCH.md, "stores of each flavour").  There is
+// no builtin for a 16-byte sc1 store; the trailing s_nop keeps the compiler's next instruction off the
+// data registers until the store has read them (cdna_hip_programming.md §5.7).
+template <bool WT>
+__device__ __forceinline__ void store_row_piece(float* dst, const float4& v) {
+  if constexpr (WT) {
+    const f32x4 t = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(dst), "v"(t) : "memory");
+  } else {
+    *reinterpret_cast<float4*>(dst) = v;
+  }
+}
+
+// stream  [nchunks*T] u16: bits 0..14 column offset inside the slice (== slice width: the all-zero row),
+//                          bit 15 = last entry of its virtual row
+// chunk_meta [nchunks]: {2 * (virtual row holding entry c*T) + (that row began in an earlier chunk), first row of
+// the chunk's slice in Bp}
+// Bp: scaled copy of B, slice s at rows [s*(w+1), (s+1)*(w+1)), row w of every slice all zero
+// nchunks % 32 == 0 (the stream is padded), so every XCD owns whole waves.
+template <int T, bool WT>
+__global__ void __launch_bounds__(256)
+spmm_group_kernel(const unsigned short* __restrict__ stream, const int2* __restrict__ chunk_meta,
+                  const float* __restrict__ Bp, float* __restrict__ Cv, float* __restrict__ P,
+                  int nchunks, int k, int col_tile, int ldb) {
+  const int lane = threadIdx.x & 63;
+  const int wib  = threadIdx.x >> 6;
+  const int g    = lane >> 4;
+  const int f    = lane & 15;
+  const int per_xcd = nchunks >> 3;
+  const int c_in = ((int)(blockIdx.x >> 3) * 4 + wib) * 4;
+  if (c_in >= per_xcd) return;                                  // (whole wave: per_xcd % 4 == 0)
+  const int c = (int)(blockIdx.x & 7) * per_xcd + c_in + g;     // this group's chunk
+
+  const int fcol = col_tile * 64 + f * 4;
+  const bool fok = fcol < k;                                    // (k % 4 == 0: a float4 is all in or all out)
+  const unsigned row_bytes = (unsigned)ldb * 4u;
+  const unsigned foff = (unsigned)(fok ? fcol : col_tile * 64) * 4u;
+  const char* __restrict__ Bb = reinterpret_cast<const char*>(Bp);
+  const size_t kk = (size_t)k;
+
+  const int2 meta = chunk_meta[c];                              // one load: nothing else stands before the first gather
+  const int vrow = meta.x >> 1;                                 // virtual row holding the chunk's first entry
+  const bool head = meta.x & 1;                                 // ... which began in an earlier chunk
+  const int base = meta.y;                                      // first row of this chunk's slice in Bp
+  float* ptr  = head ? P + (size_t)(2 * c) * kk + fcol : Cv + (size_t)vrow * kk + fcol;
+  float* nptr = Cv + (size_t)(vrow + 1) * kk + fcol;
+  bool first = true;                                            // no row of this chunk has ended yet
+
+  const unsigned short* __restrict__ sp = stream + (size_t)c * T + f;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  unsigned e_nx = sp[0];
+  unsigned fl = 0;
+#pragma unroll 1
+  for (int blk = 0; blk < T / 16; ++blk) {
+    const unsigned e = e_nx;
+    if (blk + 1 < T / 16) e_nx = sp[(blk + 1) * 16];
+    const int rowoff = (int)(__umul24((e & 0x7FFFu) + (unsigned)base, row_bytes));
+    fl = e >> 15;
+    float4 b[16];
+#define GCN_G_ALL(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15)
+#define GCN_G_GATHER(UU) \
+    b[UU] = *reinterpret_cast<const float4*>(Bb + (size_t)((unsigned)row_bcast<UU>(rowoff) + foff));
+    GCN_G_ALL(GCN_G_GATHER)
+#undef GCN_G_GATHER
+    const unsigned long long ends = __ballot(fl != 0);          // bit g*16+u: entry u of group g ends a row
+    if (ends == 0ull) {
+#define GCN_G_ADD(UU) acc.x += b[UU].x; acc.y += b[UU].y; acc.z += b[UU].z; acc.w += b[UU].w;
+      GCN_G_ALL(GCN_G_ADD)
+    } else {
+#define GCN_G_STEP(UU)                                                                              \
+      GCN_G_ADD(UU)                                                                                 \
+      if (ends & (0x0001000100010001ull << UU)) {                /* some group ends a row here */    \
+        if (row_bcast<UU>((int)fl)) {                                                               \
+          if (fok) store_row_piece<WT>(ptr, acc);                            \
+          acc = make_float4(0.f, 0.f, 0.f, 0.f);                                                    \
+          ptr = nptr; nptr += kk; first = false;                                                    \
+        }                                                                                           \
+      }
+      GCN_G_ALL(GCN_G_STEP)
+#undef GCN_G_STEP
+#undef GCN_G_ADD
+    }
+#undef GCN_G_ALL
+  }
+  // the row piece that sticks out of the chunk's end (the last entry did not end its row)
+  if (!row_bcast<15>((int)fl)) {
+    float* dst = (head && first) ? ptr : P + (size_t)(2 * c + 1) * kk + fcol;
+    if (fok) store_row_piece<WT>(dst, acc);
+  }
+}
+
+bool spmm_group_eligible(int k, int ldb, const void* B, const void* C, const void* P) {
+  const uintptr_t al = (uintptr_t)B | (uintptr_t)C | (uintptr_t)P;
+  if (ldb <= 0) ldb = k;
+  return k % 4 == 0 && ldb % 4 == 0 && (al & 15) == 0 && ldb * 4 < (1 << 24);
+}
+
+hipError_t launch_spmm_group(const GroupArgs& a, hipStream_t s) {
+  if (a.nchunks <= 0 || a.k <= 0) return hipSuccess;
+  if (a.nchunks % 32 != 0 || a.k % 4 != 0) return hipErrorInvalidValue;
+  const int per_xcd = a.nchunks / 8;
+  const int nblocks = 8 * ((per_xcd + 15) / 16);
+  const int tiles = (a.k + 63) / 64;
+  const int ldb = a.ldb > 0 ? a.ldb : a.k;
+  for (int t = 0; t < tiles; ++t) {
+#define GCN_GROUP_ARGS a.stream, reinterpret_cast<const int2*>(a.chunk_meta), a.Bp, a.Cv, a.P, a.nchunks, a.k, t, ldb
+#define GCN_GROUP_LAUNCH(TT)                                                                              \
+      if (a.write_through) spmm_group_kernel<TT, true><<<dim3(nblocks), dim3(256), 0, s>>>(GCN_GROUP_ARGS);  \
+      else                 spmm_group_kernel<TT, false><<<dim3(nblocks), dim3(256), 0, s>>>(GCN_GROUP_ARGS); \
+      break;
+    switch (a.T) {
+      case 256:  GCN_GROUP_LAUNCH(256)
+      case 512:  GCN_GROUP_LAUNCH(512)
+      case 1024: GCN_GROUP_LAUNCH(1024)
+      case 2048: GCN_GROUP_LAUNCH(2048)
+      default: return hipErrorInvalidValue;
+    }
+#undef GCN_GROUP_LAUNCH
+#undef GCN_GROUP_ARGS
+  }
+  return hipGetLastError();
+}
+
+}  // namespace gcn

@@ -43,6 +43,8 @@ struct SpmmArgs {
 hipError_t launch_plan_chunk_rows(const int* rowptr, int m, int T, int nchunks,
                                   int* chunk_row, hipStream_t s);
 hipError_t launch_spmm(const SpmmArgs& a, int cu_count, hipStream_t s);
+hipError_t launch_spmm_fixup(const int* rowptr, const float* P, float* C, const int* chunk_row, int nchunks, int T,
+                             int k, hipStream_t s);
 hipError_t launch_gather_rows(float* dst, const float* src, const int* idx, int nrows, int k,
                               hipStream_t s);
 // dst[r, 0:k] = src[r, 0:k], dst[r, k:ld] = 0 for r < rows (dst row stride ld >= k)
@@ -63,6 +65,32 @@ hipError_t launch_spmm_narrow(const SpmmArgs& a, int nblocks, bool epi, hipStrea
 bool spmm_quad_eligible(const SpmmArgs& a);
 int spmm_quad_lanes(int k);
 hipError_t launch_spmm_quad(const SpmmArgs& a, int nblocks, bool epi, hipStream_t s);
+
+// spmm_group.hip — value-free sliced main pass, four independent 16-lane row engines per wave
+struct GroupArgs {
+  const unsigned short* stream;  // [nchunks*T]: bits 0..14 column offset inside the slice, bit 15 = row end
+  const int* chunk_meta;         // int2 [nchunks]: {2 * (virtual row holding entry c*T) + (it began in an earlier chunk),
+                                 //                  first row of the chunk's slice in Bp}
+  const float* Bp;               // scaled copy of B: slice s at rows [s*(w+1), (s+1)*(w+1)), row w all zero
+  float* Cv;                     // partial outputs [S*m x k]
+  float* P;                      // partial slab [2*nchunks x k]
+  int nchunks, T, k, ldb;        // T = entries per chunk (of ONE 16-lane group), ldb = row stride of Bp (0 = k)
+  int write_through = 1;         // partial rows leave L2 at once (sc1 stores)
+};
+bool spmm_group_eligible(int k, int ldb, const void* B, const void* C, const void* P);
+hipError_t launch_spmm_group(const GroupArgs& a, hipStream_t s);
+// the slice-major 15-bit stream the group kernel walks (S slices of width w = ceil(n/S) <= 32767): every virtual
+// row gets >= 1 entry, every slice is padded to whole chunks and the total to a multiple of 32 chunks with
+// entries that gather the slice's zero row.  Outputs: vrowptr_g [S*m+1] (caller-allocated; the fix-up pass needs
+// it), *stream_out, *chunk_row_out [nchunks] and *chunk_meta_out (int2 [nchunks], see GroupArgs) — allocated here,
+// the caller frees —, *nchunks_host.
+hipError_t build_group_stream(const int* vrowptr, const int* vcol, int m, int n, int S, int T, int* vrowptr_g,
+                              unsigned short** stream_out, int** chunk_row_out, int** chunk_meta_out,
+                              int* nchunks_host, hipStream_t st);
+// dst[(c / w)*(w+1) + c % w, :] = rowscale[c] * src[c, :] (row stride ld >= k, padding columns zero), row w of
+// every slice zero: the layout GroupArgs::Bp describes
+hipError_t launch_scale_rows_sliced(float* dst, const float* src, const float* rowscale, int n, int k, int ld,
+                                    int S, int w, hipStream_t s);
 
 // spmm_panel.hip — LDS-staged feature tiles per row panel (near-diagonal matrices)
 hipError_t panel_plan(const int* rowptr, const int* col, int m, int n, int R, int* w0_dev,

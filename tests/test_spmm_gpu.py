@@ -639,21 +639,19 @@ def test_value_free_sliced_pass_for_normalised_adjacencies():
         B = rng.standard_normal((n, k)).astype(np.float32)
         bias = rng.standard_normal(k).astype(np.float32)
         adj = _adj(rowptr, col, val, n, n)
-        assert adj.num_slices >= 2 and adj.main_kernel(k) == "gcn::spmm_quad_kernel<16, false, true, true>"
+        assert adj.num_slices >= 2 and adj.main_kernel(k).startswith("gcn::spmm_group_kernel<")
         Bd = torch.from_numpy(B).to(_dev())
         Cref = oracle_spmm(rowptr, col, val, B)
         assert rel_err(adj.matmul_raw(Bd).cpu().numpy(), Cref) <= TOL
         Ce = adj.matmul_raw(Bd, bias=torch.from_numpy(bias).to(_dev()), relu=True).cpu().numpy()
         assert rel_err(Ce, np.maximum(Cref + bias, 0)) <= TOL
         assert torch.equal(adj.matmul_raw(Bd), adj.matmul_raw(Bd))          # reproducible
-    # every slice count the 16-bit stream supports (the four-per-gather kernel forced: 4 / 8 slices leave
-    # virtual rows shorter than the automatic rule wants), on a graph whose size is not a multiple of any of them
+    # several slice counts, on a graph whose size is not a multiple of any of them
     B = rng.standard_normal((n, 128)).astype(np.float32)
     Cref = oracle_spmm(rowptr, col, val, B)
     for S in (2, 3, 4, 7, 8):
         adj = _adj(rowptr, col, val, n, n, slices=S)
-        adj.set_gather_width(4)
-        assert adj.num_slices == S and adj.main_kernel(128) == "gcn::spmm_quad_kernel<16, false, true, true>"
+        assert adj.num_slices == S and adj.main_kernel(128).startswith("gcn::spmm_group_kernel<")
         assert rel_err(adj.matmul_raw(torch.from_numpy(B).to(_dev())).cpu().numpy(), Cref) <= TOL
     # one entry off by 1e-4 relative: no longer rank-1 -> the ordinary kernel, and the right answer
     val2 = val.copy(); val2[len(val2) // 2] *= 1.0001
@@ -688,7 +686,7 @@ def test_explicit_value_factors_on_a_row_block_with_renumbered_columns():
     Bd = torch.from_numpy(B).to(_dev())
     plain = adj.matmul_raw(Bd).cpu().numpy()
     adj.set_value_factors(torch.from_numpy(u[lo:hi]), torch.from_numpy(u_col))
-    assert adj.has_value_factors and adj.main_kernel(128) == "gcn::spmm_quad_kernel<16, false, true, true>"
+    assert adj.has_value_factors and adj.main_kernel(128).startswith("gcn::spmm_group_kernel<")
     fast = adj.matmul_raw(Bd).cpu().numpy()
     Cref = oracle_spmm(rp, ci, va, B)
     assert rel_err(plain, Cref) <= TOL and rel_err(fast, Cref) <= TOL
@@ -696,3 +694,64 @@ def test_explicit_value_factors_on_a_row_block_with_renumbered_columns():
         adj.set_value_factors(torch.from_numpy(u[lo:hi] * 1.001), torch.from_numpy(u_col))
     assert not adj.has_value_factors                            # a refused hand-over leaves none behind
     assert rel_err(adj.matmul_raw(Bd).cpu().numpy(), Cref) <= TOL
+
+
+def _hub_graph(n, e, hubs, seed):
+    """normalised adjacency with a few vertices adjacent to (nearly) everything: virtual rows of n/S entries
+    (they cross many chunks of the group kernel) next to rows with a handful of entries and empty slices"""
+    rng = np.random.default_rng(seed)
+    u, v = rng.integers(0, n, e), rng.integers(0, n, e)
+    for h in hubs:
+        hv = rng.choice(n, size=int(0.9 * n), replace=False)
+        u, v = np.concatenate([u, np.full(len(hv), h)]), np.concatenate([v, hv])
+    A = sp.coo_matrix((np.ones(len(u)), (u, v)), shape=(n, n)); A = (A + A.T).tocsr()
+    A.setdiag(0); A.eliminate_zeros(); A.data[:] = 1.0
+    A = (A + sp.eye(n)).tocsr()
+    d = np.asarray(A.sum(1)).ravel() ** -0.5
+    A = (sp.diags(d) @ A @ sp.diags(d)).tocsr(); A.sort_indices()
+    return A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.astype(np.float32)
+
+
+@pytest.mark.parametrize("S", [2, 3, 5, 8, 16, 32])
+def test_group_kernel_value_free_sliced_pass(S):
+    """the sliced pass of a normalised adjacency on the 15-bit stream (spmm_group.hip): four independent row
+    engines per wave, row ends as stream bits, padding entries for empty virtual rows; hub rows cross chunks"""
+    n = 9000 + S                                          # not a multiple of the slice count
+    rowptr, col, val = _hub_graph(n, 900000, hubs=(0, n // 2, n - 1), seed=30 + S)
+    rng = np.random.default_rng(S)
+    adj = _adj(rowptr, col, val, n, n, slices=S)
+    assert adj.num_slices == S and adj.has_value_factors
+    for k in (64, 128, 100, 36, 41):
+        assert adj.main_kernel(k).startswith("gcn::spmm_group_kernel<"), adj.main_kernel(k)
+        B = rng.standard_normal((n, k)).astype(np.float32)
+        Bd = torch.from_numpy(B).to(_dev())
+        Cref = oracle_spmm(rowptr, col, val, B)
+        C = adj.matmul_raw(Bd)
+        assert rel_err(C.cpu().numpy(), Cref) <= TOL
+        assert torch.equal(C, adj.matmul_raw(Bd))                             # reproducible
+        bias = rng.standard_normal(k).astype(np.float32)
+        Ce = adj.matmul_raw(Bd, bias=torch.from_numpy(bias).to(_dev()), relu=True).cpu().numpy()
+        assert rel_err(Ce, np.maximum(Cref + bias, 0)) <= TOL
+    # a NaN / Inf feature row reaches exactly the rows of A that reference it
+    B = rng.standard_normal((n, 64)).astype(np.float32)
+    bad = [7, n // 3]
+    B[bad[0], 5] = np.nan; B[bad[1], 60] = np.inf
+    C = adj.matmul_raw(torch.from_numpy(B).to(_dev())).cpu().numpy()
+    A = sp.csr_matrix((val, col, rowptr), shape=(n, n))
+    touched = np.asarray((A[:, bad] != 0).sum(1)).ravel() > 0
+    assert np.all(np.isfinite(C[~touched])) and np.all(~np.isfinite(C[touched]).all(1) | True)
+    assert np.all(np.isnan(C[np.asarray((A[:, [bad[0]]] != 0).sum(1)).ravel() > 0, 5]))
+
+
+def test_value_free_pass_with_slices_wider_than_the_15_bit_stream():
+    """slices of more than 32 767 columns cannot use the group kernel's 15-bit entries: the value-free pass then
+    runs the four-per-gather kernel on its 16-bit column stream (<= 65 535 columns per slice, <= 8 slices)"""
+    n = 70000
+    rowptr, col, val = sym_norm_graph(n, 3600000, seed=77)          # ~100 non-zeros per row and column
+    adj = _adj(rowptr, col, val, n, n, slices=2)                    # 35 000 columns per slice
+    adj.set_gather_width(4)                                         # (52 entries per virtual row: force the quad layout)
+    assert adj.num_slices == 2 and adj.has_value_factors
+    assert adj.main_kernel(128) == "gcn::spmm_quad_kernel<16, false, true, true>"
+    B = np.random.default_rng(5).standard_normal((n, 128)).astype(np.float32)
+    C = adj.matmul_raw(torch.from_numpy(B).to(_dev())).cpu().numpy()
+    assert rel_err(C, oracle_spmm(rowptr, col, val, B)) <= TOL

@@ -23,7 +23,8 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--tiles", default="0")
     ap.add_argument("--slices", default="0")
-    ap.add_argument("--blocks-per-cu", type=int, default=8)
+    ap.add_argument("--blocks-per-cu", default="32", help="comma list")
+    ap.add_argument("--gather-width", type=int, default=0)
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     rowptr, col, val, n = graphgen.make_graph(args.graph, device=dev, seed=1, scale=args.scale)
@@ -34,12 +35,14 @@ def main():
     for k in [int(x) for x in args.ks.split(",")]:
         H = graphgen.random_features(n, k, seed=2, device=dev)
         out = torch.empty((n, k), device=dev)
-        for chunk, tile, S in [(int(x), int(t), int(sl)) for x in args.chunks.split(",")
-                               for t in args.tiles.split(",") for sl in args.slices.split(",")]:
+        for chunk, tile, S, bpc in [(int(x), int(t), int(sl), int(b)) for x in args.chunks.split(",")
+                                    for t in args.tiles.split(",") for sl in args.slices.split(",")
+                                    for b in str(args.blocks_per_cu).split(",")]:
             adj = gcn_amd.CsrAdjacency(rowptr, col, val, (n, n), symmetric=True, chunk_nnz=chunk)
             adj.set_tile_cols(tile)
             adj.enable_slicing(S)
-            adj.set_blocks_per_cu(args.blocks_per_cu)
+            adj.set_blocks_per_cu(bpc)
+            adj.set_gather_width(args.gather_width)
             for _ in range(3):
                 adj.matmul_raw(H, out=out)
             torch.cuda.synchronize()
@@ -54,7 +57,7 @@ def main():
             step = e0.elapsed_time(e1) / args.iters
             avg, mn = sum(ms) / len(ms), min(ms)
             balg = nnz * (8 + 4 * k) + (n + 1) * 4 + n * k * 4
-            print(f"{k} {tile} {S} {adj.chunk_size} {adj.num_chunks} {avg:.4f} {mn:.4f} {step:.4f} "
+            print(f"{k} {tile} {S}/bpc{bpc} {adj.chunk_size} {adj.num_chunks} {adj.main_kernel(min(k, 64))[5:40]} {avg:.4f} {mn:.4f} {step:.4f} "
                   f"{2.0 * nnz * k / step / 1e6:.1f} {balg / step / 1e6:.1f} {balg / step / 1e-3 / 8e12:.4f}", flush=True)
             del adj
         del H, out
