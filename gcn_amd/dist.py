@@ -1,17 +1,29 @@
 """1-D row partition of Â across the GPUs of one node + all-gather of layer outputs.
 
-The reference is single-GPU (device 0 hard-coded, flexspmm.cu:507); this module is the
-MI355X-native extension BASELINE.json asks for: rank p owns a contiguous,
-nnz-balanced row block Â[rows_p, :], computes H'_p = Â[rows_p, :] · H with the same HIP
-kernel, and the next layer's input H' is assembled with ONE RCCL all-gather over xGMI.
+The reference is single-GPU (device 0 hard-coded, flexspmm.cu:507; 32-bit `row*k` offsets, flexspmm.cu:67;
+column indices stored as floats, tile.cu:67); this module is the MI355X-native extension BASELINE.json asks
+for: rank p owns a contiguous row block Â[rows_p, :], computes H'_p = Â[rows_p, :] · H with the same HIP
+kernel, and the next layer's input H' is assembled with ONE exchange per layer over xGMI.
 
-Zero-copy layout: shards have unequal row counts, so every shard is padded to
-`max_rows` and the gathered buffer is [world * max_rows, k].  Instead of compacting
-that buffer after every layer, the column indices of the local block are remapped ONCE
-to the padded numbering (col' = owner(col) * max_rows + local_index(col)); the local
-SpMM writes straight into this rank's slot of the buffer and the all-gather is done
-in place.  Summation order inside a row is unchanged by the partition, so every row
-equals the single-GPU result bit for bit.
+A rank is built from ITS OWN block only (`from_row_block`: local row pointer, GLOBAL int64 column ids,
+values, the row boundaries of all ranks) — the whole graph never has to exist on any rank, and its global
+non-zero count may exceed 2³¹ (papers100M: 3.3 G); only a rank's block must fit int32.  The whole-graph
+constructor is a convenience for graphs that do fit.
+
+Zero-copy layout: shards have unequal row counts, so every shard is padded to `max_rows` and the gathered
+buffer is [world * max_rows, k].  Instead of compacting that buffer after every layer, the column indices
+of the local block are remapped ONCE (on the device) to the padded numbering
+(col' = owner(col) * max_rows + local_index(col), int32); the local SpMM writes straight into this rank's
+slot of the buffer and the exchange is done in place.  Summation order inside a row is unchanged by the
+partition, so every row equals the single-GPU result to rounding.
+
+Exchange forms (`exchange=`): "all_gather" — one RCCL all-gather per layer (`all_gather_into_tensor` on
+nccl, the list form on gloo; chosen once from the backend, never by catching an error: a rank-local
+failure must not make one rank issue a different collective than its peers); "direct" — every rank sends
+its shard to each peer and receives theirs in ONE grouped batch of point-to-point operations
+(`batch_isend_irecv`): on MI355X every GPU pair has its own xGMI link, so each shard crosses exactly one
+link once, where a ring all-gather forwards every shard over world-1 hops.  Both forms fill
+the same buffer with the same bytes.
 """
 import numpy as np
 import torch
@@ -31,6 +43,17 @@ def partition_rows(rowptr, world, balance="nnz"):
     return np.maximum.accumulate(np.minimum(bounds, m))
 
 
+class _Works:
+    """what batch_isend_irecv returns, behind the one-handle interface of an async collective"""
+
+    def __init__(self, works):
+        self.works = works
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+
+
 class RowShardedAdjacency:
     """This rank's row block of Â in the padded-gather numbering.
 
@@ -39,26 +62,64 @@ class RowShardedAdjacency:
     inject an oracle-backed stand-in (the product path has no CPU compute).
     """
 
-    def __init__(self, rowptr, col, val, n, rank, world, make_local, balance="nnz", value_factor=None):
+    def __init__(self, rowptr, col, val, n, rank, world, make_local, balance="nnz", value_factor=None,
+                 exchange="all_gather"):
+        """Whole-graph convenience constructor: every rank passes the same CSR (int32 rowptr/col on the
+        device); the partition is derived from it and this rank keeps its block."""
         rowptr_h = rowptr.detach().cpu().numpy().astype(np.int64)
-        self.n, self.rank, self.world = int(n), int(rank), int(world)
+        bounds = partition_rows(rowptr_h, world, balance)
+        lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+        e_lo, e_hi = int(rowptr_h[lo]), int(rowptr_h[hi])
+        local_rowptr = torch.from_numpy(rowptr_h[lo:hi + 1] - e_lo).to(col.device)
+        self._setup(local_rowptr, col[e_lo:e_hi], val[e_lo:e_hi], bounds, rank, world, make_local,
+                    value_factor, int(rowptr_h[-1]), exchange)
+        if int(n) != self.n:
+            raise ValueError("n does not match the row pointer")
+
+    @classmethod
+    def from_row_block(cls, local_rowptr, local_col, local_val, bounds, rank, world, make_local,
+                       value_factor=None, total_nnz=None, exchange="all_gather"):
+        """A rank from its own row block: `local_rowptr` [rows+1] (starts at 0), `local_col` GLOBAL column
+        ids (any integer dtype; int64 for graphs past 2³¹ columns·entries), `local_val` fp32, `bounds`
+        [world+1] the first global row of every rank's block (the same on all ranks)."""
+        self = cls.__new__(cls)
+        self._setup(local_rowptr, local_col, local_val, np.asarray(bounds, dtype=np.int64), rank, world,
+                    make_local, value_factor, total_nnz, exchange)
+        return self
+
+    def _setup(self, local_rowptr, gcol, val, bounds, rank, world, make_local, value_factor, total_nnz, exchange):
+        if exchange not in ("all_gather", "direct"):
+            raise ValueError("exchange must be 'all_gather' or 'direct'")
+        self.rank, self.world, self.exchange = int(rank), int(world), exchange
+        self.bounds = np.asarray(bounds, dtype=np.int64)
+        if len(self.bounds) != self.world + 1 or self.bounds[0] != 0 or np.any(np.diff(self.bounds) < 0):
+            raise ValueError("bounds must be world+1 non-decreasing row boundaries starting at 0")
+        self.n = int(self.bounds[-1])
         self.collective = True     # False = compute this rank's block only (single-GPU rehearsal of rank r of W)
-        self.bounds = partition_rows(rowptr_h, world, balance)
-        sizes = np.diff(self.bounds)
-        self.max_rows = int(sizes.max())
+        self.max_rows = int(np.diff(self.bounds).max())
+        if self.world * self.max_rows >= 2 ** 31:
+            raise ValueError("padded column space does not fit int32")
         self.row_lo, self.row_hi = int(self.bounds[rank]), int(self.bounds[rank + 1])
         self.rows = self.row_hi - self.row_lo
-        device = col.device
-        e_lo, e_hi = int(rowptr_h[self.row_lo]), int(rowptr_h[self.row_hi])
-        local_rowptr = torch.from_numpy((rowptr_h[self.row_lo:self.row_hi + 1] - e_lo).astype(np.int32)).to(device)
-        gcol = col[e_lo:e_hi].long()
+        device = gcol.device
+        if int(local_rowptr.numel()) != self.rows + 1:
+            raise ValueError("local_rowptr must have rows+1 entries")
+        self.local_nnz = int(gcol.numel())
+        if self.local_nnz >= 2 ** 31:
+            raise ValueError("a rank's block must hold fewer than 2^31 non-zeros (use more ranks)")
+        self.total_nnz = int(total_nnz) if total_nnz is not None else None
         bounds_t = torch.from_numpy(self.bounds).to(device)
-        owner = torch.bucketize(gcol, bounds_t[1:], right=True)
-        pcol = owner * self.max_rows + (gcol - bounds_t[owner])
-        self.local_nnz = e_hi - e_lo
-        self.total_nnz = int(rowptr_h[-1])
-        self._local_args = (local_rowptr, pcol.to(torch.int32), val[e_lo:e_hi].contiguous(),
-                            (self.rows, self.world * self.max_rows))
+        self._bounds_t = bounds_t
+        # global column id -> padded numbering, on the device, in pieces (the temporaries are int64)
+        pcol = torch.empty(self.local_nnz, dtype=torch.int32, device=device)
+        step = 1 << 26
+        for s in range(0, self.local_nnz, step):
+            g = gcol[s:s + step].long()
+            owner = torch.bucketize(g, bounds_t[1:], right=True)
+            pcol[s:s + step] = (owner * self.max_rows + (g - bounds_t[owner])).to(torch.int32)
+            del g, owner
+        self._local_args = (local_rowptr.to(device=device, dtype=torch.int32).contiguous(), pcol,
+                            val.to(torch.float32).contiguous(), (self.rows, self.world * self.max_rows))
         self._make_local = make_local
         # value_factor: u [n] with Â[r, c] = u[r]·u[c] (u = D^-1/2 of a normalised adjacency).  The row block
         # with renumbered columns still factors — as u[rows] x u in the padded numbering — and telling the
@@ -68,33 +129,56 @@ class RowShardedAdjacency:
             u = value_factor.to(device=device, dtype=torch.float32)
             self._factors = (u[self.row_lo:self.row_hi].contiguous(), self.to_padded(u[:, None])[:, 0].contiguous())
         self.local = self._new_local()
-        self._bounds_t = bounds_t
 
-    # global [n, k] -> padded [world*max_rows, k]
+    # -- global <-> padded numbering (device side) ---------------------------------------------
+    def _pad_index(self, device):
+        idx = torch.arange(self.n, dtype=torch.int64, device=device)
+        b = self._bounds_t.to(device)
+        owner = torch.bucketize(idx, b[1:], right=True)
+        return owner * self.max_rows + (idx - b[owner])
+
     def to_padded(self, H):
+        """global [n, k] -> padded [world*max_rows, k] (rows of rank p at p*max_rows ...; the rest zero)"""
         out = torch.zeros((self.world * self.max_rows, H.shape[1]), dtype=H.dtype, device=H.device)
-        for p in range(self.world):
-            lo, hi = int(self.bounds[p]), int(self.bounds[p + 1])
-            out[p * self.max_rows: p * self.max_rows + (hi - lo)] = H[lo:hi]
+        out.index_copy_(0, self._pad_index(H.device), H)
         return out
 
-    # padded [world*max_rows, k] -> global [n, k]
     def from_padded(self, Hp):
-        parts = []
-        for p in range(self.world):
-            lo, hi = int(self.bounds[p]), int(self.bounds[p + 1])
-            parts.append(Hp[p * self.max_rows: p * self.max_rows + (hi - lo)])
-        return torch.cat(parts, 0)
+        """padded [world*max_rows, k] -> global [n, k]"""
+        return Hp.index_select(0, self._pad_index(Hp.device))
 
     def new_buffer(self, k, device, dtype=torch.float32):
         return torch.zeros((self.world * self.max_rows, k), dtype=dtype, device=device)
 
-    def _all_gather(self, out_padded, slot, group, async_op):
-        try:
+    # -- the exchange ---------------------------------------------------------------------------
+    def collective_form(self, group=None):
+        """which operation a layer's exchange issues (decided from the backend, once)"""
+        if self.world == 1 or not self.collective:
+            return "none"
+        if self.exchange == "direct":
+            return "batch_isend_irecv (direct exchange, one shard per peer link)"
+        return "all_gather_into_tensor" if dist.get_backend(group) == "nccl" else "all_gather (list form)"
+
+    def _exchange(self, out_padded, slot, group, async_op):
+        if self.exchange == "direct":
+            ops = []
+            for off in range(1, self.world):               # staggered peer order: rank r starts with r+1
+                peer = (self.rank + off) % self.world
+                src = (self.rank - off) % self.world
+                dst_view = out_padded[src * self.max_rows: (src + 1) * self.max_rows]
+                ops.append(dist.P2POp(dist.isend, slot, dist.get_global_rank(group, peer) if group is not None else peer,
+                                      group=group))
+                ops.append(dist.P2POp(dist.irecv, dst_view, dist.get_global_rank(group, src) if group is not None else src,
+                                      group=group))
+            works = _Works(dist.batch_isend_irecv(ops))
+            if async_op:
+                return works
+            works.wait()
+            return None
+        if dist.get_backend(group) == "nccl":
             return dist.all_gather_into_tensor(out_padded, slot, group=group, async_op=async_op)
-        except (RuntimeError, NotImplementedError):         # backends without the flat form
-            views = [out_padded[p * self.max_rows: (p + 1) * self.max_rows] for p in range(self.world)]
-            return dist.all_gather(views, slot.clone(), group=group, async_op=async_op)
+        views = [out_padded[p * self.max_rows: (p + 1) * self.max_rows] for p in range(self.world)]
+        return dist.all_gather(views, slot.clone(), group=group, async_op=async_op)
 
     def another_local(self):
         """A second operator over the same row block (own plan, own workspaces) — what lets two
@@ -111,30 +195,25 @@ class RowShardedAdjacency:
         return local
 
     def layer_async(self, H_padded, out_padded, group=None, local=None):
-        """Like layer(), but the all-gather is only ENQUEUED (on the communicator's stream, behind
+        """Like layer(), but the exchange is only ENQUEUED (on the communicator's stream, behind
         the SpMM that fills the slot); returns the Work handle (None for world == 1).  The caller
-        waits on it before the next read of out_padded — this is what lets the all-gather of one
+        waits on it before the next read of out_padded — this is what lets the exchange of one
         column plane overlap the SpMM of the next (PipelinedAggregation)."""
         slot = out_padded[self.rank * self.max_rows: (self.rank + 1) * self.max_rows]
         if self.rows:
             (local or self.local).matmul_raw(H_padded, out=slot[: self.rows])
         if self.world > 1 and self.collective:
-            return self._all_gather(out_padded, slot, group, True)
+            return self._exchange(out_padded, slot, group, True)
         return None
 
     def layer(self, H_padded, out_padded, group=None):
         """out = Â · H for the whole graph, in the padded layout, on every rank:
-        local row-block SpMM into this rank's slot, then one in-place all-gather."""
-        k = H_padded.shape[1]
+        local row-block SpMM into this rank's slot, then one in-place exchange."""
         slot = out_padded[self.rank * self.max_rows: (self.rank + 1) * self.max_rows]
         if self.rows:
             self.local.matmul_raw(H_padded, out=slot[: self.rows])
         if self.world > 1 and self.collective:
-            try:
-                dist.all_gather_into_tensor(out_padded, slot, group=group)
-            except (RuntimeError, NotImplementedError):     # backends without the flat form
-                views = [out_padded[p * self.max_rows: (p + 1) * self.max_rows] for p in range(self.world)]
-                dist.all_gather(views, slot.clone(), group=group)
+            self._exchange(out_padded, slot, group, False)
         return out_padded
 
 
@@ -143,10 +222,10 @@ class PipelinedAggregation:
 
     The k feature columns are kept as independent PLANES of ≤ `plane_cols` columns (each plane a
     padded [world·max_rows, cols] buffer pair).  Â·H acts on every column independently, so
-    plane p of layer l+1 depends only on the gathered plane p of layer l: while RCCL all-gathers
+    plane p of layer l+1 depends only on the gathered plane p of layer l: while RCCL moves
     plane p over xGMI on its own stream, the compute stream already runs the SpMM of plane p+1
     (and, at the layer seam, plane 0 of the next layer).  Per layer every rank still does all of
-    its row-block SpMM work and one all-gather per plane; only the waiting is gone.  Plane width 64
+    its row-block SpMM work and one exchange per plane; only the waiting is gone.  Plane width 64
     is also the kernel's preferred column tile when n·256 B fits the Infinity Cache.
     """
 
@@ -157,7 +236,7 @@ class PipelinedAggregation:
         self.dst = [shard.new_buffer(w, device) for w in self.widths]
         self.pending = [None] * len(self.widths)
         # One HIP stream and one operator (plan + workspaces) per plane: the planes' chains
-        # (SpMM passes -> fix-up -> slice reduction -> all-gather) are independent, so on separate
+        # (SpMM passes -> fix-up -> slice reduction -> exchange) are independent, so on separate
         # streams the short tail kernels and launch gaps of one plane hide under the main kernel of the
         # other (rank-0 share of an 8-way partition of the Reddit-shaped graph, compute only: 0.546 ->
         # 0.501 ms per layer, profiles/r01f_sim8_streams.log).  Off on the CPU (gloo tests) and for a single plane.
@@ -179,15 +258,21 @@ class PipelinedAggregation:
             self.src[p].copy_(self.shard.to_padded(H[:, c:c + w].contiguous()))
             c += w
 
+    def load_padded_block(self, fill):
+        """fill(plane_index, buffer[world*max_rows, width]) writes the planes' source buffers in place — for
+        features that only ever exist in the padded layout (graphs whose global [n, k] matrix is never built)"""
+        for p, buf in enumerate(self.src):
+            fill(p, buf)
+
     def _one_plane(self, p):
         if self.pending[p] is not None:
-            self.pending[p].wait()                  # the gather that produced src[p]
+            self.pending[p].wait()                  # the exchange that produced src[p]
             self.pending[p] = None
         self.pending[p] = self.shard.layer_async(self.src[p], self.dst[p], self.group, local=self.locals[p])
         self.src[p], self.dst[p] = self.dst[p], self.src[p]
 
     def step(self):
-        """one aggregation layer over all planes (all-gathers left in flight)"""
+        """one aggregation layer over all planes (exchanges left in flight)"""
         if self.streams is None:
             for p in range(len(self.widths)):
                 self._one_plane(p)
@@ -214,6 +299,12 @@ class PipelinedAggregation:
                 self.pending[p] = None
 
     def result(self):
-        """global [n, k] view of the current layer output (waits for outstanding gathers)"""
+        """global [n, k] view of the current layer output (waits for outstanding exchanges)"""
         self.finish()
         return torch.cat([self.shard.from_padded(b) for b in self.src], 1)
+
+    def local_rows(self):
+        """this rank's own rows of the current layer output, [rows, k] (no global matrix involved)"""
+        self.finish()
+        lo = self.shard.rank * self.shard.max_rows
+        return torch.cat([b[lo: lo + self.shard.rows] for b in self.src], 1)

@@ -152,7 +152,9 @@ def make_rmat_row_block(n, directed_edges, world, rank, abcd=(0.57, 0.19, 0.19, 
     self-loops added, Â = D^-1/2 (A+I) D^-1/2.  The sample stream is regenerated once per row block
     (same seed → same graph) so that only one block's entries are ever resident; the degrees of ALL
     vertices (needed for the values) come out of those passes.
-    → (rowptr[int32, rows+1], col[int32], val[fp32], n, row_lo, row_hi) with GLOBAL column indices."""
+    → (rowptr[int32, rows+1], col[int32], val[fp32], n, row_lo, row_hi, deg[int64, n]) with GLOBAL column
+    indices; deg = stored entries per row of the WHOLE graph (self-loop included), so Â = diag(u)·(A+I)·diag(u)
+    with u = deg^-1/2 and the global non-zero count is deg.sum()."""
     device = torch.device(device)
     rows_per = (n + world - 1) // world
     pgen = torch.Generator(device=device)
@@ -194,7 +196,62 @@ def make_rmat_row_block(n, directed_edges, world, rank, abcd=(0.57, 0.19, 0.19, 
     rowptr[1:] = torch.cumsum(torch.bincount(rows, minlength=hi - lo), 0)
     dinv = deg.to(torch.float64).pow(-0.5)
     val = (dinv[rows + lo] * dinv[cols]).to(torch.float32)
-    return rowptr.to(torch.int32), cols.to(torch.int32), val, n, lo, hi
+    return rowptr.to(torch.int32), cols.to(torch.int32), val, n, lo, hi, deg
+
+
+def value_factor_from_degrees(deg):
+    """u [n] fp32 with fl32(Â[r, c]) = u[r]·u[c] to within a few ulp: the square root of the stored diagonal
+    fl32(deg^-1) — what gcn_spmm_plan_enable_slicing derives by itself when it sees a whole square matrix."""
+    dinv = deg.to(torch.float64).pow(-0.5)
+    return (dinv * dinv).to(torch.float32).sqrt()
+
+
+def make_graph_row_block(name, world, rank, device="cpu", seed=1, scale=1.0, balance="nnz"):
+    """Row block `rank` of the `world`-way contiguous, nnz-balanced row partition of make_graph(name, ...) —
+    built WITHOUT materialising the whole CSR: the undirected edge keys (one int64 per edge) and the degree
+    vector are the only whole-graph objects, the block's entries are selected and sorted on their own.
+    → (local_rowptr[int32], col[int64, GLOBAL ids], val[fp32], n, bounds[np.int64, world+1], u[fp32, n],
+       total_nnz); identical, entry for entry, to slicing make_graph's result (tests/test_graphgen.py)."""
+    import numpy as np
+    spec = SHAPES[name]
+    n = max(16, int(spec["n"] * scale))
+    edges = max(n, int(spec["edges"] * scale))
+    edges = min(edges, n * (n - 1) // 2)
+    keys = rmat_undirected_edges(n, edges, spec["abcd"], seed=seed, device=device)
+    device = keys.device
+    u, v = keys // n, keys % n
+    del keys
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed + 1000)
+    perm = torch.randperm(n, generator=gen, device=device)
+    u, v = perm[u], perm[v]
+    deg = torch.bincount(u, minlength=n) + torch.bincount(v, minlength=n) + 1
+    rowptr_g = torch.zeros(n + 1, dtype=torch.int64, device=device)
+    rowptr_g[1:] = torch.cumsum(deg, 0)
+    total = int(rowptr_g[-1])
+    if balance == "rows":
+        bounds = np.array([(n * p) // world for p in range(world + 1)], dtype=np.int64)
+    else:                                                     # as dist.partition_rows, on the device
+        targets = torch.tensor([(total * p) // world for p in range(1, world)], dtype=torch.int64, device=device)
+        cuts = torch.searchsorted(rowptr_g, targets, right=False).cpu().numpy() if world > 1 else np.zeros(0, np.int64)
+        bounds = np.maximum.accumulate(np.minimum(np.concatenate([[0], cuts, [n]]).astype(np.int64), n))
+    lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+    parts = []
+    for r, c in ((u, v), (v, u)):
+        m = (r >= lo) & (r < hi)
+        parts.append((r[m] - lo) * n + c[m])
+    del u, v
+    loops = torch.arange(lo, hi, dtype=torch.int64, device=device)
+    parts.append((loops - lo) * n + loops)
+    key = torch.sort(torch.cat(parts)).values
+    del parts
+    rows, cols = key // n, key % n
+    del key
+    local_rowptr = torch.zeros(hi - lo + 1, dtype=torch.int64, device=device)
+    local_rowptr[1:] = torch.cumsum(torch.bincount(rows, minlength=hi - lo), 0)
+    dinv = deg.to(torch.float64).pow(-0.5)
+    val = (dinv[rows + lo] * dinv[cols]).to(torch.float32)
+    return local_rowptr.to(torch.int32), cols, val, n, bounds, value_factor_from_degrees(deg), total
 
 
 def random_features(n, k, seed=2, device="cpu"):

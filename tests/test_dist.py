@@ -39,15 +39,30 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, balance, q):
+def _worker(rank, world, port, balance, q, exchange="all_gather", from_block=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         n, k = 700, 24
         rp, ci, va = sym_norm_graph(n, 6000, seed=3)
         H = torch.from_numpy(np.random.default_rng(1).standard_normal((n, k)).astype(np.float32))
-        shard = RowShardedAdjacency(torch.from_numpy(rp), torch.from_numpy(ci), torch.from_numpy(va), n,
-                                    rank, world, _OracleLocal, balance=balance)
+        if from_block:
+            # the rank is handed ITS rows only: local row pointer, GLOBAL int64 column ids, values, all ranks' bounds
+            bounds = partition_rows(rp, world, balance)
+            lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+            e0, e1 = int(rp[lo]), int(rp[hi])
+            shard = RowShardedAdjacency.from_row_block(
+                torch.from_numpy((rp[lo:hi + 1] - e0).astype(np.int32)), torch.from_numpy(ci[e0:e1].astype(np.int64)),
+                torch.from_numpy(va[e0:e1]), bounds, rank, world, _OracleLocal, total_nnz=len(ci), exchange=exchange)
+            whole = RowShardedAdjacency(torch.from_numpy(rp), torch.from_numpy(ci), torch.from_numpy(va), n,
+                                        rank, world, _OracleLocal, balance=balance)
+            for x, y in zip(shard._local_args[:3], whole._local_args[:3]):      # the same block, bit for bit
+                assert torch.equal(x, y)
+            assert shard._local_args[3] == whole._local_args[3] and shard.max_rows == whole.max_rows
+        else:
+            shard = RowShardedAdjacency(torch.from_numpy(rp), torch.from_numpy(ci), torch.from_numpy(va), n,
+                                        rank, world, _OracleLocal, balance=balance, exchange=exchange)
+        assert ("isend" in shard.collective_form()) == (exchange == "direct")
         a, b = shard.to_padded(H), shard.new_buffer(k, "cpu")
         shard.layer(a, b)            # layer 1
         shard.layer(b, a)            # layer 2 consumes the all-gathered output of layer 1
@@ -68,12 +83,16 @@ def _worker(rank, world, port, balance, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,balance", [(2, "nnz"), (3, "nnz"), (2, "rows")])
-def test_row_sharded_layers_match_single_process(world, balance):
+@pytest.mark.parametrize("world,balance,exchange,from_block",
+                         [(2, "nnz", "all_gather", False), (3, "nnz", "all_gather", False), (2, "rows", "all_gather", False),
+                          (2, "nnz", "direct", False), (3, "nnz", "direct", True), (2, "nnz", "all_gather", True)])
+def test_row_sharded_layers_match_single_process(world, balance, exchange, from_block):
+    """whole-graph and own-block constructors, all-gather and direct (grouped send/recv) exchange: every
+    combination reproduces the unsharded layers bit for bit"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, balance, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, balance, q, exchange, from_block)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=240) for _ in range(world)]
@@ -96,3 +115,31 @@ def test_partition_rows_balances_nnz_and_covers_all_rows():
         assert per.sum() == rowptr[-1]
         assert per.max() <= rowptr[-1] / world + 5000          # within one (hub) row of the ideal
     assert np.array_equal(partition_rows(rowptr, 4, "rows"), [0, 250, 500, 750, 1000])
+
+
+def test_from_row_block_remaps_global_int64_ids_and_refuses_what_cannot_fit():
+    """the rank gets GLOBAL int64 column ids and remaps them itself to the padded int32 numbering
+    (owner * max_rows + index inside the owner's block) — nothing whole-graph is needed; a padded space or a
+    block that cannot fit int32 is refused up front"""
+    world, rank = 4, 2
+    bounds = np.array([0, 5, 12, 15, 30], dtype=np.int64)        # unequal blocks: max_rows = 15
+    lrp = torch.tensor([0, 2, 2, 5], dtype=torch.int32)          # this rank's 3 rows
+    gcol = torch.tensor([4, 29, 5, 11, 14], dtype=torch.int64)
+    seen = {}
+
+    def make_local(rp, ci, va, shape):
+        seen["args"] = (rp, ci, va, shape)
+        return object()
+
+    shard = RowShardedAdjacency.from_row_block(lrp, gcol, torch.ones(5), bounds, rank, world, make_local)
+    rp, ci, va, shape = seen["args"]
+    assert shape == (3, 4 * 15) and ci.dtype == torch.int32 and shard.n == 30 and shard.rows == 3
+    assert ci.tolist() == [0 * 15 + 4, 3 * 15 + 14, 1 * 15 + 0, 1 * 15 + 6, 2 * 15 + 2]
+    H = torch.arange(30, dtype=torch.float32)[:, None]
+    assert torch.equal(shard.from_padded(shard.to_padded(H)), H)
+    assert shard.to_padded(H)[3 * 15 + 14, 0] == 29 and shard.to_padded(H)[5, 0] == 0   # (padding rows stay zero)
+    with pytest.raises(ValueError):                               # world * max_rows must stay below 2^31
+        RowShardedAdjacency.from_row_block(lrp, gcol, torch.ones(5), np.array([0, 3, 2 ** 30, 2 ** 30 + 1, 2 ** 30 + 2]),
+                                           0, world, make_local)
+    with pytest.raises(ValueError):
+        RowShardedAdjacency.from_row_block(lrp, gcol, torch.ones(5), bounds, rank, world, make_local, exchange="ring")

@@ -39,7 +39,8 @@ def test_row_blocks_of_a_graph_too_large_to_hold_whole_tile_one_symmetric_normal
     n, samples, world = 3000, 40000, 4
     mats, seen = [], 0
     for r in range(world):
-        rp, ci, va, nn, lo, hi = graphgen.make_rmat_row_block(n, samples, world, r, device="cpu", seed=4, batch=1 << 13)
+        rp, ci, va, nn, lo, hi, deg = graphgen.make_rmat_row_block(n, samples, world, r, device="cpu", seed=4, batch=1 << 13)
+        assert torch.equal(deg[lo:hi], (rp[1:] - rp[:-1]).long())        # whole-graph degrees come with every block
         assert nn == n and lo == seen and rp.dtype == torch.int32 and ci.dtype == torch.int32 and va.dtype == torch.float32
         seen = hi
         rows = np.repeat(np.arange(hi - lo), np.diff(rp.numpy()))
@@ -55,3 +56,23 @@ def test_row_blocks_of_a_graph_too_large_to_hold_whole_tile_one_symmetric_normal
     # deterministic
     again = graphgen.make_rmat_row_block(n, samples, world, 1, device="cpu", seed=4, batch=1 << 13)
     assert torch.equal(again[1], graphgen.make_rmat_row_block(n, samples, world, 1, device="cpu", seed=4, batch=1 << 13)[1])
+
+
+def test_rank_local_row_blocks_equal_slices_of_the_whole_graph():
+    """make_graph_row_block builds a rank's block of the nnz-balanced partition without the whole CSR; stacked,
+    the blocks are make_graph's matrix entry for entry, the bounds are dist.partition_rows', and the value
+    factor reproduces the values"""
+    import numpy as np
+    from gcn_amd.dist import partition_rows
+    rp, ci, va, n = graphgen.make_graph("reddit", device="cpu", seed=1, scale=0.004)
+    for world in (1, 3):
+        want = partition_rows(rp.numpy(), world)
+        for r in range(world):
+            lrp, col, val, nn, bounds, u, total = graphgen.make_graph_row_block("reddit", world, r, device="cpu", seed=1, scale=0.004)
+            assert nn == n and total == int(ci.numel()) and np.array_equal(bounds, want) and col.dtype == torch.int64
+            lo, hi = int(bounds[r]), int(bounds[r + 1])
+            e0, e1 = int(rp[lo]), int(rp[hi])
+            assert torch.equal(lrp.long(), rp[lo:hi + 1].long() - e0)
+            assert torch.equal(col, ci[e0:e1].long()) and torch.equal(val, va[e0:e1])
+            rows = torch.repeat_interleave(torch.arange(lo, hi), (lrp[1:] - lrp[:-1]).long())
+            assert float(((u[rows] * u[col] - val).abs() / val).max()) < 4e-7

@@ -67,3 +67,23 @@ def sym_norm_graph(n, e, seed):
     d = np.asarray(A.sum(1)).ravel() ** -0.5
     A = (sp.diags(d) @ A @ sp.diags(d)).tocsr(); A.sort_indices()
     return A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.astype(np.float32)
+
+
+def sampled_rows_oracle_err(rowptr_dev, col_dev, val_dev, B_dev, C_dev, rows):
+    """rel. error of C_dev[rows] against the fp64 C oracle on a compacted copy of the sampled rows: only the rows
+    of B the sample references travel to the host (full-size configs: B has tens of GB).  All *_dev are torch
+    tensors on one device; rows a sorted numpy int64 array.  → (rel_err, entries_checked)"""
+    import torch
+    dev = C_dev.device
+    r = torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(dev)
+    rp = rowptr_dev.long()
+    start, lens = rp[r], rp[r + 1] - rp[r]
+    seg = torch.repeat_interleave(torch.arange(len(rows), device=dev), lens)
+    first = torch.cumsum(lens, 0) - lens
+    e = start[seg] + (torch.arange(int(lens.sum()), device=dev) - first[seg])
+    cols = col_dev[e].long()
+    uniq, inv = torch.unique(cols, return_inverse=True)
+    sub_rp = np.zeros(len(rows) + 1, np.int32)
+    sub_rp[1:] = np.cumsum(lens.cpu().numpy())
+    Cref = oracle_spmm(sub_rp, inv.to(torch.int32).cpu().numpy(), val_dev[e].cpu().numpy(), B_dev[uniq].cpu().numpy())
+    return rel_err(C_dev[r].cpu().numpy(), Cref), int(e.numel())

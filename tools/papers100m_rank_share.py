@@ -33,7 +33,7 @@ def main():
     n = int(111059956 * args.scale)
     samples = int(1615685872 * args.scale)
     t0 = time.time()
-    rowptr, col, val, n, lo, hi = graphgen.make_rmat_row_block(n, samples, args.world, args.rank, device=dev, seed=4)
+    rowptr, col, val, n, lo, hi, _deg = graphgen.make_rmat_row_block(n, samples, args.world, args.rank, device=dev, seed=4)
     torch.cuda.synchronize()
     m, nnz, k = hi - lo, int(col.numel()), args.k
     print(f"# block rows [{lo}, {hi}) of n={n}: m={m} nnz={nnz} mean_deg={nnz / m:.1f} "
