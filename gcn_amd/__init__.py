@@ -8,8 +8,8 @@
 Drop-in shared objects for gcn6.py live in gcn_amd/dropin/ (see INTEGRATION.md).
 """
 from ._lib import GcnAmdError, LIB_PATH, DROPIN_DIR, load as load_library  # noqa: F401
-from .spmm import CsrAdjacency, spmm, gather_rows, install, uninstall  # noqa: F401
+from .spmm import CsrAdjacency, spmm, gather_rows, dropout_rows, install, uninstall  # noqa: F401
 from . import reorder, dropin  # noqa: F401
 from .layers import GCN, GraphConvolution, GraphConvolution2  # noqa: F401
 
-__version__ = "0.1.0"
+__version__ = "0.2.0"

@@ -30,6 +30,9 @@ SIGNATURES = {
     "gcn_spmm_plan_workspace_bytes": (ctypes.c_size_t, [_c_p, _c_i32]),
     "gcn_spmm_csr_f32": (ctypes.c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i32, _c_p]),
     "gcn_spmm_csr_f32_bias_relu": (ctypes.c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i32, _c_i32, _c_p]),
+    "gcn_spmm_csr_f32_epilogue": (ctypes.c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i32, ctypes.c_float,
+                                                 ctypes.c_uint64, ctypes.c_uint64, _c_i32, _c_p]),
+    "gcn_dropout_f32": (ctypes.c_int, [_c_p, _c_p, ctypes.c_int64, ctypes.c_float, ctypes.c_uint64, ctypes.c_uint64, _c_p]),
     "gcn_spmm_plan_set_tile_cols": (ctypes.c_int, [_c_p, _c_i32]),
     "gcn_spmm_plan_set_blocks_per_cu": (ctypes.c_int, [_c_p, _c_i32]),
     "gcn_spmm_plan_set_gather_width": (ctypes.c_int, [_c_p, _c_i32]),

@@ -1,0 +1,763 @@
+// api_spmm.cpp — the native C ABI of libgcnspmm.so: the SpMM plan and the SpMM itself (see
+// include/gcn_spmm.h for the contract and the reference interfaces each entry point replaces).  The
+// reorderers' entry points are in api_reorder.cpp, the reference's own symbols (flexspmm, csr2tile, ...)
+// in api_dropin.cpp.
+#include "plan.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <new>
+
+#define GCN_VERSION_STR "0.2.0"
+
+namespace gcn {
+
+std::mutex g_plan_mu;
+
+int cu_count_cached() {
+  static int cached[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return -1;
+  if (dev < 0 || dev >= 64) return -1;
+  if (cached[dev] > 0) return cached[dev];
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
+  cached[dev] = prop.multiProcessorCount;
+  return cached[dev];
+}
+
+// chunk size: the largest power of two <= nnz / resident waves (8 blocks x 4 waves per CU), within
+// [64, 2048].  Measured (profiles/r01_sweep_chunk_size.txt): every chunk boundary costs a partial
+// row (slab write + fix-up read) and a row-pointer restart, and that outweighs the load imbalance of
+// having only one or two chunks per wave — Reddit-shaped 1 GPU: T = 512 / 1024 / 2048 / 4096 ->
+// 4.12 / 4.03 / 3.94 / 4.04 ms; rank of an 8-way partition: T = 64 / 512 / 2048 / 4096 ->
+// 0.68 / 0.56 / 0.556 / 0.67 ms.
+int auto_chunk_nnz(long long nnz, int cu) {
+  if (cu <= 0) cu = 256;
+  const long long waves = (long long)cu * 32;
+  const long long per_wave = nnz / waves;
+  long long t = 64;
+  while (t * 2 <= per_wave && t < 2048) t *= 2;
+  return (int)t;
+}
+
+// Feature-column tile per pass.  Measured on MI355X (profiles/r01_sweep_tiles_*.txt): when one
+// 64-column slice of B (n x 256 B) sits well inside the 256 MiB Infinity Cache, k/64 narrow
+// passes beat one wide pass by 3-6 % (Reddit-shaped, n = 233 k); when it does not (products-
+// shaped, n = 2.4 M) the widest tile wins by 6-7 %.
+int auto_tile_cols(long long n, int k) {
+  if (k <= 64) return 0;
+  const long long budget = 128LL << 20;          // half of the Infinity Cache
+  if (n * 256 <= budget) return 64;
+  if (n * 512 <= budget && k > 128) return 128;
+  return 0;                                      // widest tile k allows (<= 256 columns)
+}
+
+namespace {
+
+bool env_on(const char* name) { const char* e = std::getenv(name); return !e || e[0] != '0'; }
+int env_int(const char* name, int dflt) { const char* e = std::getenv(name); return e ? std::atoi(e) : dflt; }
+
+// development knobs, read once per process (DESIGN.md lists them)
+bool valless_enabled() { static const bool v = env_on("GCN_AMD_VALLESS"); return v; }   // value-free sliced pass
+bool col16_enabled() { static const bool v = env_on("GCN_AMD_COL16"); return v; }       // its 16-bit column stream (quad kernel)
+bool group_enabled() { static const bool v = env_on("GCN_AMD_GROUP"); return v; }       // the group kernel (spmm_group.hip)
+bool group_sc1() { static const bool v = env_on("GCN_AMD_GROUP_SC1"); return v; }       // write-through partial-row stores
+int group_chunk() {                                                                     // entries per 16-lane group chunk
+  static const int v = [] { const int t = env_int("GCN_AMD_GROUP_T", 512); return (t == 256 || t == 512 || t == 1024 || t == 2048) ? t : 512; }();
+  return v;
+}
+int slice_min_k() { static const int v = env_int("GCN_AMD_SLICE_MIN_K", 33); return v; }  // smallest k the sliced copy is used for
+
+// Expected 128-byte cache lines one gathered feature row costs, summed over its 64-column tiles, when B's
+// rows are `ld` floats apart (the row start offsets cycle through the multiples of gcd(4*ld, 128)).
+double lines_per_row(int k, int ld) {
+  const long long row_bytes = 4LL * ld;
+  long long g = row_bytes % 128;
+  for (long long a = 128; g != 0;) { const long long t = a % g; a = g; g = t; if (g == 0) { g = a; break; } }
+  if (g == 0) g = 128;                                // row_bytes % 128 == 0: every row starts on a line
+  const int period = (int)(128 / g);
+  double total = 0;
+  for (int r = 0; r < period; ++r) {
+    const long long off = (r * row_bytes) % 128;
+    for (long long t0 = 0; t0 < 4LL * k; t0 += 256) {
+      const long long w = (4LL * k - t0) < 256 ? (4LL * k - t0) : 256;
+      const long long start = (off + t0) % 128;
+      total += (double)((start + w - 1) / 128 + 1);
+    }
+  }
+  return total / period;
+}
+
+}  // namespace
+
+bool pad_b_enabled() { static const bool v = env_on("GCN_AMD_PAD_B"); return v; }
+
+// Row stride (floats) B is gathered with: k itself, or k rounded up to whole 128-byte lines when that
+// saves >= 15 % of the cache lines per gathered row and the re-laid table stays <= 768 MiB.  Measured
+// (profiles/r01f_sweep_padded_feature_rows.log, whole SpMM, unpadded -> padded): Reddit-shaped k = 20:
+// 2.19 -> 1.60 ms, 24: 2.26 -> 1.60, 47: 2.11 -> 2.00, 100: 4.43 -> 3.84, 172: 7.56 -> 5.73; no saving
+// by the model and none measured for k = 40, 48 (rows of 160 / 192 B never straddle more lines than
+// padded ones); products-shaped k = 47 (627 MB padded): 5.41 -> 4.86 ms, k = 100 (1.25 GB): 8.95 ->
+// 9.73 ms — past the Infinity Cache the larger table and the copy cost more than the lines save.
+int padded_ldb(long long n, int k) {
+  if (k <= 16 || k % 32 == 0 || !pad_b_enabled()) return k;
+  const int ld = (k + 31) / 32 * 32;
+  if ((long long)sizeof(float) * n * ld > (768LL << 20)) return k;
+  return lines_per_row(k, k) >= 1.15 * lines_per_row(k, ld) ? ld : k;
+}
+
+// Number of column slices for the XCD-aware slicing (slicing.hip), 0 = do not slice.
+// Measured on MI355X with the r01f kernels (profiles/r01f_sweep_slices_scales.log; Reddit-shaped graphs
+// of 14.5 k .. 1.86 M vertices, mean degree 493; whole SpMM, k = 128, best S in brackets):
+//   n = 14.5 k (64-column table 3.7 MB): slicing buys nothing;  29 k (7.5 MB): [2] 0.352 vs 0.394 ms
+//   unsliced;  58 k: [4] 0.84 vs 1.18;  116 k: [4/8] 1.76-1.80 vs 3.13;  233 k: [8] 3.62 vs 7.3;
+//   466 k: [8] 9.20 vs 15.7 (16: 9.84);  932 k: [8] 24.4 vs 32.3;  1.86 M: [8] 56.5 vs 62.5.
+// So: as many slices as bring one slice of the table (n/S x 256 B) down to the 4 MiB of an XCD's L2,
+// but never more than the 8 XCDs — beyond 8 every XCD walks several slices and the extra partial rows
+// (S*m*k floats written and re-read) cost more than the higher hit rate returns (r02 group kernel, n = 233 k,
+// whole SpMM: S = 8 / 12 / 16 / 24: 3.21 / 3.23 / 3.31 / 3.65 ms, profiles/r02d_*).  Needs >= 16
+// non-zeros per virtual row; at mean degree 51 (products-shaped) slicing loses and stays off.
+int auto_slices(long long m, long long n, long long nnz) {
+  if (m <= 0 || nnz <= 0) return 0;
+  static const int forced = env_int("GCN_AMD_SLICES", -1);
+  if (forced >= 0) return forced;                     // development knob: the slice count "auto" resolves to
+  if (nnz / m < 128) return 0;                        // low degree: partial rows outweigh the hits
+  const long long table = n * 256;                    // bytes of one 64-column tile of B
+  if (table <= (4LL << 20)) return 0;                 // fits every L2 as it is
+  int S = 2;
+  while (S < 8 && table / S > (4LL << 20)) S *= 2;
+  while (S > 1 && nnz / m / S < 16) S /= 2;           // keep >= 16 non-zeros per virtual row
+  if (S < 2) return 0;
+  // slices far larger than any cache (huge n): the partial rows cost traffic and buy no hits
+  if (table / S > (64LL << 20)) return 0;
+  return S;
+}
+
+void die(const char* what, hipError_t e) {
+  std::fprintf(stderr, "libgcnspmm: %s failed: %s\n", what, hipGetErrorString(e));
+  std::abort();
+}
+
+bool verbose() {
+  const char* v = std::getenv("GCN_AMD_VERBOSE");
+  return v && v[0] && v[0] != '0';
+}
+
+// The stateless entry points (oneshot / cuspmm / flexspmm) keep their partial slab and chunk rows in a
+// scratch plan per (device, stream): two calls that can run concurrently never share buffers.  The plans
+// are never freed (a static destructor would call hipFree after the runtime has shut down).
+gcn_spmm_plan* scratch_plan(void* stream) {
+  static auto* plans = new std::map<std::pair<int, void*>, gcn_spmm_plan*>();
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  auto& slot = (*plans)[{dev, stream}];
+  if (!slot) { slot = new (std::nothrow) gcn_spmm_plan(); if (slot) slot->device = dev; }
+  return slot;
+}
+
+}  // namespace gcn
+
+using gcn::g_plan_mu;
+
+namespace {
+
+size_t ws_elems(const gcn_spmm_plan* p, int k) {
+  int chunks = std::max(p->nchunks, p->panels.out_nchunks);
+  chunks = std::max(chunks, p->col16.nchunks16);
+  chunks = std::max(chunks, p->group.nchunks);
+  return 2 * (size_t)(chunks > 0 ? chunks : 1) * (size_t)k;
+}
+
+// grow-only scratch of a plan; plans may be shared between host threads, so growth is serialised
+template <class T>
+int grow(gcn::DevBuf<T>& buf, size_t count) {
+  std::lock_guard<std::mutex> lk(g_plan_mu);
+  return buf.grow(count) == hipSuccess ? GCN_OK : GCN_ERR_ALLOC;
+}
+
+bool sliced_for(const gcn_spmm_plan* p, int k) { return p->slicing.S > 0 && p->nnz > 0 && k >= gcn::slice_min_k(); }
+
+// would the sliced launch of a k-wide SpMM run a value-free kernel (and is the scaled copy of B worth it)?
+bool valless_pays(const gcn_spmm_plan* p, int k, int ldb) {
+  // (the scaled copy of B costs 2*n*k*4 bytes of traffic whatever the matrix; the value stream it saves is
+  //  4 bytes per non-zero plus instructions — measured break-even near 65 non-zeros per column of the
+  //  block: the rank-0 share of an 8-way partition of the Reddit-shaped graph (62 per column) does not gain)
+  if (!sliced_for(p, k) || !p->factors.ready() || p->panels.R != 0 || p->nnz / p->n < 96) return false;
+  if (p->group.ready() && gcn::spmm_group_eligible(k, ldb, nullptr, nullptr, nullptr)) return true;   // spmm_group.hip
+  gcn::SpmmArgs t{};                                   // the launch as the sliced branch will issue it
+  t.k = k; t.nnz = p->nnz; t.n = p->n; t.nchunks_grid = p->nchunks; t.T = p->T;
+  t.m = p->slicing.S * p->m; t.ldb = ldb; t.tile_cols = p->tile_cols ? p->tile_cols : 64;
+  t.gather_width = p->gather_width;
+  return gcn::spmm_will_use_quad(t) && gcn::spmm_quad_lanes(k) == 16;
+}
+
+// the value-free pass of this plan runs the group kernel (its scaled copy of B is then laid out slice by slice)
+bool group_pass(const gcn_spmm_plan* p) { return p->group.ready(); }
+
+// Widths that are not a multiple of 4 take a detour over k' = k rounded up to 4 (gcn_spmm_csr_f32_epilogue); it
+// exists to reach the 16-byte-per-lane kernels, so it follows their rule: the four-per-gather kernel only pays
+// from ~48 non-zeros per (virtual) row up, the group kernel of the value-free pass does not mind short rows
+bool odd_width_detour(const gcn_spmm_plan* p, int k) {
+  if (!(k > 16 && k % 4 != 0 && p->nnz > 0 && p->panels.R == 0 && p->gather_width != 1 && gcn::pad_b_enabled())) return false;
+  const int kp = (k + 3) / 4 * 4, ldb = (kp + 31) / 32 * 32;
+  if ((long long)sizeof(float) * p->n * ldb > (768LL << 20)) return false;
+  if (p->gather_width == 4) return true;
+  const bool sliced = sliced_for(p, k);
+  if (sliced && p->group.ready() && p->factors.ready() && p->nnz / p->n >= 96) return true;
+  const long long rows = sliced ? (long long)p->slicing.S * p->m : (long long)p->m;
+  return rows > 0 && p->nnz / rows >= 48;
+}
+
+// Copy of B the sliced main pass gathers from: rows `ldb` floats apart (>= k, padding columns zero), scaled by
+// u_col when `scaled`; one all-zero row more than B has (16-bit stream) or, for the group kernel, slice s at
+// rows [s*(w+1), (s+1)*(w+1)) with row w of every slice zero.
+int relay_B(gcn_spmm_plan* p, const float* B, int k, int ldb, bool scaled, hipStream_t st) {
+  if (scaled && group_pass(p)) {
+    const size_t rows = (size_t)p->slicing.S * (size_t)(p->group.w + 1);
+    const int rc = grow(p->bpad, rows * (size_t)ldb);
+    if (rc != GCN_OK) return rc;
+    return gcn::launch_scale_rows_sliced(p->bpad, B, p->factors.u_col, p->n, k, ldb, p->slicing.S, p->group.w, st) == hipSuccess
+               ? GCN_OK : GCN_ERR_HIP;
+  }
+  const int rc = grow(p->bpad, ((size_t)p->n + 1) * (size_t)ldb);
+  if (rc != GCN_OK) return rc;
+  if (gcn::launch_pad_rows(p->bpad, B, p->n, k, ldb, st, scaled ? p->factors.u_col : nullptr) != hipSuccess ||
+      hipMemsetAsync(p->bpad + (size_t)p->n * ldb, 0, sizeof(float) * (size_t)ldb, st) != hipSuccess)
+    return GCN_ERR_HIP;
+  return GCN_OK;
+}
+
+struct Epilogue {                                      // C = dropout(act(A*B + bias))
+  const float* bias = nullptr;
+  int relu = 0;
+  gcn::DropoutSpec drop;
+};
+
+// b_ld: row stride of B in floats when the caller of this function has already re-laid it, 0 = k;
+// b_scaled: that copy's rows are already scaled by u_col (value-free pass).
+// *dropped: set when the dropout mask has been applied by a pass of this function (the slice reduction carries
+// it); otherwise the caller applies it in place afterwards.
+int spmm_impl(gcn_spmm_plan* p, const int32_t* rowptr, const int32_t* col, const float* val, const float* B, int b_ld,
+              bool b_scaled, float* C, const Epilogue& epi, int32_t k, hipStream_t st, bool* dropped) {
+  *dropped = false;
+  if (grow(p->ws, ws_elems(p, k)) != GCN_OK) return GCN_ERR_ALLOC;
+  const float* bias = epi.bias;
+  const int relu = epi.relu ? 1 : 0;
+  gcn::SpmmArgs a;
+  a.rowptr = rowptr; a.col = col; a.val = val; a.B = B; a.C = C; a.P = p->ws;
+  a.chunk_row = p->chunk_row; a.bias = bias; a.relu = relu;
+  a.nchunks = p->nchunks; a.T = p->T; a.m = p->m; a.nnz = p->nnz; a.k = k; a.n = p->n;
+  a.nnz_dev = nullptr; a.nchunks_grid = p->nchunks;
+  // narrow feature widths (k <= 32, the GCN hidden/class sizes) gather 128 B or less per
+  // non-zero: there the extra partial rows cost more than the L2 hits buy (measured 2.12 vs
+  // 2.02 ms at k = 32), so the sliced copy is used for k > 32 only
+  const bool sliced = sliced_for(p, k);
+  // Feature rows that are not a whole number of 128-byte cache lines straddle lines: a gathered row
+  // then costs up to one extra L2 request per tile.  Where that matters (padded_ldb) B is first re-laid
+  // with its rows padded to the next multiple of 32 floats (one streaming copy, ~45 us for 233 k x 100)
+  // and gathered from there; C keeps the caller's layout.  The same copy carries the row scaling of the
+  // value-free pass (values u[r]*u[c], sliced matrix): B' = diag(u) B.
+  bool valless = false;
+  if (b_ld > 0) {
+    a.ldb = b_ld;                                      // already re-laid (and maybe scaled) by the caller (odd-width path)
+    valless = b_scaled;
+  } else if (p->nnz > 0) {
+    const int ldb = gcn::padded_ldb(p->n, k);
+    valless = valless_pays(p, k, ldb);
+    if (ldb != k || valless) {
+      const int rc = relay_B(p, B, k, ldb, valless, st);
+      if (rc != GCN_OK) return rc;
+      a.B = p->bpad;
+      a.ldb = ldb;
+    }
+  }
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;             // live timing of the main kernel (gcn_spmm_profile_begin)
+  if (p->prof.armed()) { const auto pr = p->prof.next(); ev0 = pr.first; ev1 = pr.second; }
+  a.blocks_per_cu = p->blocks_per_cu;
+  a.gather_width = p->gather_width;
+  gcn::Panels& pn = p->panels;
+  if (pn.R > 0 && p->nnz > 0 && k > 32) {
+    // A = A_in + A_out: the staged part from LDS (raw sums into C), then the rest accumulated by the
+    // chunk kernel, which also carries the epilogue
+    if (ev0 && hipEventRecord(ev0, st) != hipSuccess) return GCN_ERR_HIP;
+    const int tiles = (k + 63) / 64;
+    for (int t = 0; t < tiles; ++t)
+      if (gcn::launch_panel_in(pn.in_rowptr, pn.in_off, pn.in_val, B, C, pn.w0, p->m, p->n, k, pn.R, t, st) != hipSuccess)
+        return GCN_ERR_HIP;
+    if (pn.out_nnz == 0) {
+      if (gcn::launch_panel_epilogue(C, bias, relu, p->m, k, st) != hipSuccess) return GCN_ERR_HIP;
+      if (ev1 && hipEventRecord(ev1, st) != hipSuccess) return GCN_ERR_HIP;
+      return GCN_OK;
+    }
+    a.nchunks = pn.out_nchunks; a.nchunks_grid = pn.out_nchunks;
+    a.T = pn.out_T; a.nnz = pn.out_nnz;
+    a.ev_start = nullptr; a.ev_stop = ev1;
+    if (pn.out_S > 0) {
+      // sliced: partial rows of the virtual CSR, then C += sum of the partials (+ epilogue)
+      if (grow(p->cv, (size_t)pn.out_S * (size_t)p->m * (size_t)k) != GCN_OK) return GCN_ERR_ALLOC;
+      a.rowptr = pn.out_vrowptr; a.col = pn.out_vcol; a.val = pn.out_vval; a.chunk_row = pn.out_vchunk_row;
+      a.C = p->cv; a.m = pn.out_S * p->m; a.bias = nullptr; a.relu = 0; a.accumulate = 0;
+      a.tile_cols = p->tile_cols ? p->tile_cols : 64;
+      if (gcn::launch_spmm(a, p->cu_count, st) != hipSuccess) return GCN_ERR_HIP;
+      *dropped = epi.drop.on();
+      return gcn::launch_slice_reduce(p->cv, C, bias, relu, p->m, pn.out_S, k, st, 1, nullptr, epi.drop) == hipSuccess
+                 ? GCN_OK : GCN_ERR_HIP;
+    }
+    a.rowptr = pn.out_rowptr; a.col = pn.out_col; a.val = pn.out_val;
+    a.chunk_row = pn.out_chunk_row; a.accumulate = 1;
+    a.tile_cols = p->tile_cols ? p->tile_cols : gcn::auto_tile_cols(p->n, k);
+    return gcn::launch_spmm(a, p->cu_count, st) == hipSuccess ? GCN_OK : GCN_ERR_HIP;
+  }
+  a.tile_cols = p->tile_cols ? p->tile_cols : (sliced ? 64 : gcn::auto_tile_cols(p->n, k));
+  a.ev_start = ev0; a.ev_stop = ev1;
+  if (!sliced) return gcn::launch_spmm(a, p->cu_count, st) == hipSuccess ? GCN_OK : GCN_ERR_HIP;
+
+  // sliced: the slice-major virtual CSR (S*m rows) into the partial buffer, then the per-row reduction
+  // over slices, which carries the whole epilogue (bias, ReLU, dropout mask, row factor)
+  const gcn::Slicing& sl = p->slicing;
+  if (grow(p->cv, (size_t)sl.S * (size_t)p->m * (size_t)k) != GCN_OK) return GCN_ERR_ALLOC;
+  *dropped = epi.drop.on();
+  if (valless && group_pass(p)) {
+    // four independent 16-lane row engines per wave on the 15-bit slice-major stream (spmm_group.hip)
+    gcn::GroupArgs ga;
+    ga.stream = p->group.stream; ga.chunk_meta = p->group.chunk_meta;
+    ga.Bp = a.B; ga.Cv = p->cv; ga.P = p->ws;
+    ga.nchunks = p->group.nchunks; ga.T = p->group.T; ga.k = k; ga.ldb = a.ldb;
+    ga.write_through = gcn::group_sc1() ? 1 : 0;
+    if (ev0 && hipEventRecord(ev0, st) != hipSuccess) return GCN_ERR_HIP;
+    if (gcn::launch_spmm_group(ga, st) != hipSuccess) return GCN_ERR_HIP;
+    if (ev1 && hipEventRecord(ev1, st) != hipSuccess) return GCN_ERR_HIP;
+    if (gcn::launch_spmm_fixup(p->group.vrowptr, p->ws, p->cv, p->group.chunk_row, p->group.nchunks, p->group.T, k, st) != hipSuccess)
+      return GCN_ERR_HIP;
+    return gcn::launch_slice_reduce(p->cv, C, bias, relu, p->m, sl.S, k, st, 0, p->factors.u_row, epi.drop) == hipSuccess
+               ? GCN_OK : GCN_ERR_HIP;
+  }
+  a.rowptr = sl.vrowptr; a.col = sl.vcol; a.val = sl.vval; a.chunk_row = sl.vchunk_row;
+  a.C = p->cv; a.m = sl.S * p->m; a.bias = nullptr; a.relu = 0;
+  const float* rowscale = nullptr;
+  if (valless) {                                                          // B was scaled by u_col above
+    a.valless = 1; a.val = nullptr; rowscale = p->factors.u_row;
+    const gcn::Col16Stream& c16 = p->col16;
+    if (c16.ready()) {                                                    // 16-bit column stream, slice-aligned chunks
+      a.rowptr = c16.vrowptr16; a.col = reinterpret_cast<const int*>(c16.vcol16.get()); a.chunk_row = c16.vchunk_row16;
+      a.nnz = c16.nnz16; a.nchunks = a.nchunks_grid = c16.nchunks16;
+      a.col16 = 1; a.col16_S = sl.S; a.col16_w = (p->n + sl.S - 1) / sl.S;
+      for (int i = 0; i < 9; ++i) a.col16_start[i] = c16.start16[i];
+    }
+  }
+  if (gcn::launch_spmm(a, p->cu_count, st) != hipSuccess) return GCN_ERR_HIP;
+  return gcn::launch_slice_reduce(p->cv, C, bias, relu, p->m, sl.S, k, st, 0, rowscale, epi.drop) == hipSuccess
+             ? GCN_OK : GCN_ERR_HIP;
+}
+
+// the value-free streams of a sliced plan whose values factor (built once both facts are known)
+void build_valless_streams(gcn_spmm_plan* p, hipStream_t st) {
+  gcn::Slicing& sl = p->slicing;
+  if (sl.S <= 1 || !p->factors.ready() || p->group.ready() || p->col16.ready()) return;
+  const long long vm = (long long)sl.S * p->m;
+  const int w = (p->n + sl.S - 1) / sl.S;
+  // 15-bit stream of the group kernel: slices at most 32 767 columns wide; best effort
+  if (w <= 32767 && gcn::group_enabled() && p->group.vrowptr.alloc((size_t)(vm + 1)) == hipSuccess) {
+    unsigned short* stream = nullptr;
+    int *chunk_row = nullptr, *chunk_meta = nullptr, nch = 0;
+    if (gcn::build_group_stream(sl.vrowptr, sl.vcol, p->m, p->n, sl.S, gcn::group_chunk(), p->group.vrowptr, &stream,
+                                &chunk_row, &chunk_meta, &nch, st) == hipSuccess && nch > 0) {
+      p->group.stream.adopt(stream, (size_t)nch * (size_t)gcn::group_chunk());
+      p->group.chunk_row.adopt(chunk_row, (size_t)nch);
+      p->group.chunk_meta.adopt(chunk_meta, 2 * (size_t)nch);
+      p->group.nchunks = nch; p->group.T = gcn::group_chunk(); p->group.w = w;
+      return;
+    }
+    p->group = gcn::GroupStream{};
+  }
+  // 16-bit column stream of the four-per-gather kernel (2 instead of 4 index bytes per non-zero): slices at
+  // most 65 535 columns wide, at most 8 of them; best effort — without it the 32-bit stream is used
+  if (sl.S <= 8 && w <= 65535 && gcn::col16_enabled() && p->col16.vrowptr16.alloc((size_t)(vm + 1)) == hipSuccess) {
+    gcn::Col16Stream& c = p->col16;
+    unsigned short* c16 = nullptr;
+    int nnz16 = 0;
+    if (gcn::build_col16_stream(sl.vrowptr, sl.vcol, p->m, p->n, sl.S, p->T, c.vrowptr16, &c16, &nnz16, c.start16, st) == hipSuccess &&
+        nnz16 > 0) {
+      c.vcol16.adopt(c16, (size_t)nnz16);
+      c.nnz16 = nnz16;
+      c.nchunks16 = nnz16 / p->T;
+      if (c.vchunk_row16.alloc((size_t)c.nchunks16) == hipSuccess &&
+          gcn::launch_plan_chunk_rows(c.vrowptr16, (int)vm, p->T, c.nchunks16, c.vchunk_row16, st) == hipSuccess &&
+          hipStreamSynchronize(st) == hipSuccess)
+        return;
+    }
+    p->col16 = gcn::Col16Stream{};                     // anything failed: drop the 16-bit stream
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* gcn_status_string(int s) {
+  switch (s) {
+    case GCN_OK: return "ok";
+    case GCN_ERR_INVALID_ARG: return "invalid argument";
+    case GCN_ERR_HIP: return "HIP runtime error";
+    case GCN_ERR_NO_DEVICE: return "no HIP device";
+    case GCN_ERR_CAPACITY: return "caller buffer too small";
+    case GCN_ERR_ALLOC: return "device allocation failed";
+    default: return "unknown status";
+  }
+}
+
+const char* gcn_version(void) { return GCN_VERSION_STR; }
+
+int gcn_device_cu_count(void) { return gcn::cu_count_cached(); }
+
+// ---------------------------------------------------------------------------
+int gcn_spmm_plan_create(gcn_spmm_plan_t** out, const int32_t* rowptr_dev, int32_t m, int32_t n,
+                         int32_t nnz, int32_t chunk_nnz, void* stream) {
+  if (!out || m < 0 || n < 0 || nnz < 0 || (m > 0 && !rowptr_dev)) return GCN_ERR_INVALID_ARG;
+  if (chunk_nnz < 0 || (chunk_nnz % 64) != 0) return GCN_ERR_INVALID_ARG;
+  const int cu = gcn::cu_count_cached();
+  if (cu <= 0) return GCN_ERR_NO_DEVICE;
+  gcn_spmm_plan* p = new (std::nothrow) gcn_spmm_plan();
+  if (!p) return GCN_ERR_ALLOC;
+  p->m = m; p->n = n; p->nnz = nnz; p->cu_count = cu;
+  p->T = chunk_nnz ? chunk_nnz : gcn::auto_chunk_nnz(nnz, cu);
+  p->nchunks = (int)(((long long)nnz + p->T - 1) / p->T);
+  (void)hipGetDevice(&p->device);
+  if (p->nchunks > 0) {
+    if (p->chunk_row.alloc((size_t)p->nchunks) != hipSuccess) { delete p; return GCN_ERR_ALLOC; }
+    // (synchronised: the header promises that rowptr_dev is only read during this call)
+    if (gcn::launch_plan_chunk_rows(rowptr_dev, m, p->T, p->nchunks, p->chunk_row, (hipStream_t)stream) != hipSuccess ||
+        hipStreamSynchronize((hipStream_t)stream) != hipSuccess) {
+      delete p;
+      return GCN_ERR_HIP;
+    }
+  }
+  *out = p;
+  return GCN_OK;
+}
+
+int gcn_spmm_plan_destroy(gcn_spmm_plan_t* p) {
+  delete p;                                            // every buffer and event is owned by a member
+  return GCN_OK;
+}
+
+int32_t gcn_spmm_plan_num_chunks(const gcn_spmm_plan_t* p) { return p ? p->nchunks : -1; }
+int32_t gcn_spmm_plan_chunk_nnz(const gcn_spmm_plan_t* p) { return p ? p->T : -1; }
+size_t gcn_spmm_plan_workspace_bytes(const gcn_spmm_plan_t* p, int32_t k) {
+  return (!p || k <= 0) ? 0 : sizeof(float) * ws_elems(p, k);
+}
+
+int gcn_spmm_csr_f32_epilogue(gcn_spmm_plan_t* p, const int32_t* rowptr, const int32_t* col, const float* val,
+                              const float* B, float* C, const float* bias, int32_t relu, float dropout_p,
+                              uint64_t seed, uint64_t offset, int32_t k, void* stream) {
+  if (!p || k < 0 || !(dropout_p >= 0.f && dropout_p < 1.f)) return GCN_ERR_INVALID_ARG;
+  if (p->m == 0 || k == 0) return GCN_OK;
+  if (!C || !rowptr || (p->nnz > 0 && (!col || !val || !B))) return GCN_ERR_INVALID_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  Epilogue epi;
+  epi.bias = bias; epi.relu = relu ? 1 : 0;
+  epi.drop.p = dropout_p; epi.drop.seed = seed; epi.drop.offset = offset;
+  bool dropped = false;
+  int rc;
+  // Widths that are not a multiple of 4 (class counts: 41, 47, ...) cannot use the 16-byte-per-lane
+  // kernels on the caller's layout.  They are computed at k' = k rounded up to 4 on row-padded copies:
+  // B re-laid with zero columns (stride a multiple of 32 floats), the product into a k'-wide scratch
+  // result, and one pass that compacts it into C (and applies bias / ReLU).  Reddit-shaped k = 41:
+  // 2.13 -> 1.87 ms.  Same limits as the B padding (tables <= 768 MiB), panels excluded.
+  if (odd_width_detour(p, k)) {
+    const int kp = (k + 3) / 4 * 4, ldb = (kp + 31) / 32 * 32;
+    if (grow(p->cpad, (size_t)p->m * (size_t)kp) != GCN_OK) return GCN_ERR_ALLOC;
+    const bool scaled = valless_pays(p, kp, ldb);      // the copy can carry the u_col scaling
+    if ((rc = relay_B(p, B, k, ldb, scaled, st)) != GCN_OK) return rc;
+    if ((rc = spmm_impl(p, rowptr, col, val, p->bpad, ldb, scaled, p->cpad, Epilogue{}, kp, st, &dropped)) != GCN_OK) return rc;
+    if (gcn::launch_unpad_rows(C, p->cpad, bias, epi.relu, p->m, k, kp, st) != hipSuccess) return GCN_ERR_HIP;
+    dropped = false;
+  } else {
+    if ((rc = spmm_impl(p, rowptr, col, val, B, 0, false, C, epi, k, st, &dropped)) != GCN_OK) return rc;
+  }
+  if (epi.drop.on() && !dropped)                       // no epilogue pass carried the mask: one pass in place
+    return gcn::launch_dropout(C, C, (long long)p->m * k, epi.drop, st) == hipSuccess ? GCN_OK : GCN_ERR_HIP;
+  return GCN_OK;
+}
+
+int gcn_spmm_csr_f32_bias_relu(gcn_spmm_plan_t* p, const int32_t* rowptr, const int32_t* col,
+                               const float* val, const float* B, float* C, const float* bias,
+                               int32_t relu, int32_t k, void* stream) {
+  return gcn_spmm_csr_f32_epilogue(p, rowptr, col, val, B, C, bias, relu, 0.f, 0, 0, k, stream);
+}
+
+int gcn_spmm_csr_f32(gcn_spmm_plan_t* p, const int32_t* rowptr, const int32_t* col,
+                     const float* val, const float* B, float* C, int32_t k, void* stream) {
+  return gcn_spmm_csr_f32_epilogue(p, rowptr, col, val, B, C, nullptr, 0, 0.f, 0, 0, k, stream);
+}
+
+int gcn_dropout_f32(float* dst, const float* src, int64_t count, float dropout_p, uint64_t seed, uint64_t offset,
+                    void* stream) {
+  if (count < 0 || !(dropout_p >= 0.f && dropout_p < 1.f)) return GCN_ERR_INVALID_ARG;
+  if (count == 0) return GCN_OK;
+  if (!dst || !src) return GCN_ERR_INVALID_ARG;
+  gcn::DropoutSpec d;
+  d.p = dropout_p; d.seed = seed; d.offset = offset;
+  if (!d.on()) {
+    if (dst == src) return GCN_OK;
+    return hipMemcpyAsync(dst, src, sizeof(float) * (size_t)count, hipMemcpyDeviceToDevice, (hipStream_t)stream) == hipSuccess
+               ? GCN_OK : GCN_ERR_HIP;
+  }
+  return gcn::launch_dropout(dst, src, (long long)count, d, (hipStream_t)stream) == hipSuccess ? GCN_OK : GCN_ERR_HIP;
+}
+
+int gcn_spmm_plan_enable_slicing(gcn_spmm_plan_t* p, const int32_t* rowptr, const int32_t* col,
+                                 const float* val, int32_t slices, void* stream) {
+  if (!p || slices < -1 || slices > 1024) return GCN_ERR_INVALID_ARG;
+  p->slicing = gcn::Slicing{};
+  p->col16 = gcn::Col16Stream{};
+  p->group = gcn::GroupStream{};
+  p->cv.reset();
+  const bool autom = slices == -1;
+  if (autom) slices = gcn::auto_slices(p->m, p->n, p->nnz);
+  if (slices <= 1 || p->nnz == 0 || p->m == 0) return GCN_OK;
+  if (!rowptr || !col || !val) return GCN_ERR_INVALID_ARG;
+  if ((long long)slices * p->m + 1 >= (1LL << 31)) return GCN_ERR_INVALID_ARG;
+  const long long vm = (long long)slices * p->m;
+  hipStream_t st = (hipStream_t)stream;
+  gcn::Slicing sl;
+  if (sl.vrowptr.alloc((size_t)(vm + 1)) != hipSuccess || sl.vcol.alloc((size_t)p->nnz) != hipSuccess ||
+      sl.vval.alloc((size_t)p->nnz) != hipSuccess || sl.vchunk_row.alloc((size_t)p->nchunks) != hipSuccess)
+    return GCN_ERR_ALLOC;
+  int sorted = 1;
+  if (gcn::build_sliced_csr(rowptr, col, val, p->m, p->n, p->nnz, slices, sl.vrowptr, sl.vcol, sl.vval, &sorted, st) != hipSuccess)
+    return GCN_ERR_HIP;
+  if (!sorted) return autom ? GCN_OK : GCN_ERR_INVALID_ARG;   // needs column-sorted rows; auto mode just stays unsliced
+  if (gcn::launch_plan_chunk_rows(sl.vrowptr, (int)vm, p->T, p->nchunks, sl.vchunk_row, st) != hipSuccess ||
+      hipStreamSynchronize(st) != hipSuccess)
+    return GCN_ERR_HIP;
+  sl.S = slices;
+  p->slicing = std::move(sl);
+  // Normalised adjacencies (D^-1/2 (A+I) D^-1/2) have values u[r]*u[c]: when every stored entry matches
+  // that to 4 ulp the sliced main pass can run without its value stream, on a B whose rows were scaled by u,
+  // with the row factor applied in the slice reduction.  (Factors handed over by the caller stay.)
+  if (p->m == p->n && gcn::valless_enabled() && !p->factors.ready()) {
+    gcn::DevBuf<float> u;
+    int ok = 0;
+    if (u.alloc((size_t)p->n) == hipSuccess &&
+        gcn::detect_rank1_values(rowptr, col, val, p->n, u, &ok, st) == hipSuccess && ok) {
+      p->factors.u_row = std::move(u);
+      p->factors.u_col = p->factors.u_row;
+    }
+  }
+  build_valless_streams(p, st);                        // (only once the values are known to factor)
+  return GCN_OK;
+}
+
+int32_t gcn_spmm_plan_num_slices(const gcn_spmm_plan_t* p) { return p ? p->slicing.S : -1; }
+
+int gcn_spmm_plan_set_value_factors(gcn_spmm_plan_t* p, const int32_t* rowptr, const int32_t* col,
+                                    const float* val, const float* u_row, const float* u_col, void* stream) {
+  if (!p) return GCN_ERR_INVALID_ARG;
+  p->factors = gcn::Factors{};
+  p->col16 = gcn::Col16Stream{};                       // (the value-free streams exist only beside factors)
+  p->group = gcn::GroupStream{};
+  if (!u_row && !u_col) return GCN_OK;                              // (null, null): forget the factors
+  if (!u_row || !u_col || !rowptr || (p->nnz > 0 && (!col || !val))) return GCN_ERR_INVALID_ARG;
+  if (p->m == 0 || p->nnz == 0 || !gcn::valless_enabled()) return GCN_OK;
+  hipStream_t st = (hipStream_t)stream;
+  int ok = 0;
+  if (gcn::verify_value_factors(rowptr, col, val, u_row, u_col, p->m, &ok, st) != hipSuccess) return GCN_ERR_HIP;
+  if (!ok) return GCN_ERR_INVALID_ARG;                              // some entry is not u_row[r]*u_col[c]
+  gcn::Factors f;
+  if (f.u_row.alloc((size_t)p->m) != hipSuccess || f.u_col_own.alloc((size_t)p->n) != hipSuccess) return GCN_ERR_ALLOC;
+  if (hipMemcpyAsync(f.u_row, u_row, sizeof(float) * (size_t)p->m, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+      hipMemcpyAsync(f.u_col_own, u_col, sizeof(float) * (size_t)p->n, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+      hipStreamSynchronize(st) != hipSuccess)
+    return GCN_ERR_HIP;
+  f.u_col = f.u_col_own;
+  p->factors = std::move(f);
+  build_valless_streams(p, st);
+  return GCN_OK;
+}
+
+int32_t gcn_spmm_plan_has_value_factors(const gcn_spmm_plan_t* p) { return p ? (p->factors.ready() ? 1 : 0) : -1; }
+
+int gcn_spmm_plan_enable_panels(gcn_spmm_plan_t* p, const int32_t* rowptr, const int32_t* col,
+                                const float* val, int32_t mode, void* stream) {
+  if (!p || mode < -1 || mode > 1) return GCN_ERR_INVALID_ARG;
+  p->panels = gcn::Panels{};
+  if (mode == 0 || p->nnz == 0 || p->m == 0) return GCN_OK;
+  if (!rowptr || !col || !val) return GCN_ERR_INVALID_ARG;
+  const int R = 128;
+  const int npanels = (p->m + R - 1) / R;
+  hipStream_t st = (hipStream_t)stream;
+  gcn::Panels pn;
+  if (pn.w0.alloc((size_t)npanels) != hipSuccess) return GCN_ERR_ALLOC;
+  unsigned long long inside = 0;
+  if (gcn::panel_plan(rowptr, col, p->m, p->n, R, pn.w0, &inside, st) != hipSuccess) return GCN_ERR_HIP;
+  pn.coverage = (double)inside / (double)p->nnz;
+  // automatic: only when at least half of the non-zeros are served from the staged tile
+  if (!(mode == 1 || pn.coverage >= 0.5)) { p->panels.coverage = pn.coverage; return GCN_OK; }
+  // split A = A_in + A_out on the device
+  if (pn.in_rowptr.alloc((size_t)p->m + 1) != hipSuccess || pn.out_rowptr.alloc((size_t)p->m + 1) != hipSuccess)
+    return GCN_ERR_ALLOC;
+  int nnz_in = 0;
+  if (gcn::panel_split(rowptr, col, val, pn.w0, p->m, R, pn.in_rowptr, pn.out_rowptr, nullptr, nullptr, nullptr, nullptr,
+                       &nnz_in, st) != hipSuccess)
+    return GCN_ERR_HIP;
+  const int nnz_out = p->nnz - nnz_in;
+  if (pn.in_off.alloc((size_t)nnz_in) != hipSuccess || pn.in_val.alloc((size_t)nnz_in) != hipSuccess ||
+      pn.out_col.alloc((size_t)nnz_out) != hipSuccess || pn.out_val.alloc((size_t)nnz_out) != hipSuccess)
+    return GCN_ERR_ALLOC;
+  if (gcn::panel_split(rowptr, col, val, pn.w0, p->m, R, pn.in_rowptr, pn.out_rowptr, pn.in_off, pn.in_val, pn.out_col,
+                       pn.out_val, &nnz_in, st) != hipSuccess)
+    return GCN_ERR_HIP;
+  pn.out_nnz = nnz_out;
+  pn.out_T = gcn::auto_chunk_nnz(nnz_out, p->cu_count);
+  pn.out_nchunks = (int)(((long long)nnz_out + pn.out_T - 1) / pn.out_T);
+  if (pn.out_nchunks > 0) {
+    if (pn.out_chunk_row.alloc((size_t)pn.out_nchunks) != hipSuccess) return GCN_ERR_ALLOC;
+    if (gcn::launch_plan_chunk_rows(pn.out_rowptr, p->m, pn.out_T, pn.out_nchunks, pn.out_chunk_row, st) != hipSuccess)
+      return GCN_ERR_HIP;
+  }
+  // The out-of-window part is what is LEFT of the matrix once the local structure is staged: short
+  // rows with columns all over the range, i.e. an unordered graph — the case XCD column slicing is
+  // for (slicing.hip).  Measured on the 240 k-vertex planted-partition graph (22 M left-over entries,
+  // 92 per row): slicing them 8-ways cuts the gather time only with the one-per-gather kernel (virtual
+  // rows of 11 entries: 2.49 -> 2.07 ms of kernels) and then pays 0.23 ms for the reduction — no clear
+  // win, so it stays off unless GCN_AMD_PANEL_OUT_SLICES asks for it.
+  static const int out_slices = gcn::env_int("GCN_AMD_PANEL_OUT_SLICES", 0);
+  const int S = out_slices;
+  if (S > 1 && pn.out_nchunks > 0 && (long long)S * p->m + 1 < (1LL << 31)) {
+    const long long vm = (long long)S * p->m;
+    if (pn.out_vrowptr.alloc((size_t)(vm + 1)) != hipSuccess || pn.out_vcol.alloc((size_t)nnz_out) != hipSuccess ||
+        pn.out_vval.alloc((size_t)nnz_out) != hipSuccess || pn.out_vchunk_row.alloc((size_t)pn.out_nchunks) != hipSuccess)
+      return GCN_ERR_ALLOC;
+    int sorted = 1;
+    if (gcn::build_sliced_csr(pn.out_rowptr, pn.out_col, pn.out_val, p->m, p->n, nnz_out, S, pn.out_vrowptr, pn.out_vcol,
+                              pn.out_vval, &sorted, st) != hipSuccess)
+      return GCN_ERR_HIP;
+    if (sorted && gcn::launch_plan_chunk_rows(pn.out_vrowptr, (int)vm, pn.out_T, pn.out_nchunks, pn.out_vchunk_row, st) != hipSuccess)
+      return GCN_ERR_HIP;
+    if (sorted) pn.out_S = S;                  // (unsorted rows: the unsliced out-of-window pass stays)
+  }
+  if (hipStreamSynchronize(st) != hipSuccess) return GCN_ERR_HIP;
+  pn.R = R;
+  p->panels = std::move(pn);
+  return GCN_OK;
+}
+
+int32_t gcn_spmm_plan_panel_rows(const gcn_spmm_plan_t* p) { return p ? p->panels.R : -1; }
+double gcn_spmm_plan_panel_coverage(const gcn_spmm_plan_t* p) { return p ? p->panels.coverage : -1.0; }
+
+int gcn_spmm_plan_set_tile_cols(gcn_spmm_plan_t* p, int32_t cols) {
+  if (!p || !(cols == 0 || cols == 64 || cols == 128 || cols == 256)) return GCN_ERR_INVALID_ARG;
+  p->tile_cols = cols;
+  return GCN_OK;
+}
+
+int gcn_spmm_plan_set_gather_width(gcn_spmm_plan_t* p, int32_t nz_per_gather) {
+  if (!p || (nz_per_gather != 0 && nz_per_gather != 1 && nz_per_gather != 4)) return GCN_ERR_INVALID_ARG;
+  p->gather_width = nz_per_gather;
+  return GCN_OK;
+}
+
+int gcn_spmm_plan_set_blocks_per_cu(gcn_spmm_plan_t* p, int32_t blocks) {
+  if (!p || blocks < 1 || blocks > 64) return GCN_ERR_INVALID_ARG;
+  p->blocks_per_cu = blocks;
+  return GCN_OK;
+}
+
+int32_t gcn_spmm_plan_num_passes(const gcn_spmm_plan_t* p, int32_t k) {
+  if (!p || k <= 0) return -1;
+  if (p->panels.R > 0 && k > 32) return (k + 63) / 64;
+  const int tile = p->tile_cols ? p->tile_cols : (p->slicing.S > 0 && k > 32 ? 64 : gcn::auto_tile_cols(p->n, k));
+  const int vec = gcn::pick_vec(k, tile, nullptr, nullptr, nullptr);   // 16-B aligned operands
+  return (k + 64 * vec - 1) / (64 * vec);
+}
+
+int gcn_spmm_plan_main_kernel(const gcn_spmm_plan_t* p, int32_t k, int32_t epilogue, char* buf, int32_t buflen) {
+  if (!p || k <= 0 || !buf || buflen <= 0) return GCN_ERR_INVALID_ARG;
+  if (p->panels.R > 0 && k > 32) { snprintf(buf, (size_t)buflen, "gcn::spmm_panel_in_kernel"); return GCN_OK; }
+  gcn::SpmmArgs a{};
+  const bool sliced = sliced_for(p, k);
+  a.k = k; a.n = p->n; a.m = sliced ? p->slicing.S * p->m : p->m; a.nnz = p->nnz;
+  a.nchunks_grid = p->nchunks;
+  a.relu = epilogue && !sliced ? 1 : 0;               // sliced: the epilogue runs in the slice reduction
+  a.tile_cols = p->tile_cols ? p->tile_cols : (sliced ? 64 : gcn::auto_tile_cols(p->n, k));
+  a.gather_width = p->gather_width;
+  if (odd_width_detour(p, k)) {
+    a.k = (k + 3) / 4 * 4;                             // odd widths run at k rounded up to 4 (see gcn_spmm_csr_f32_epilogue)
+    a.ldb = (a.k + 31) / 32 * 32;
+    a.relu = 0;
+    a.valless = valless_pays(p, a.k, a.ldb);
+  } else {
+    if (const int ldb = gcn::padded_ldb(p->n, k); ldb != k) a.ldb = ldb;
+    a.valless = valless_pays(p, k, a.ldb > 0 ? a.ldb : k);   // as spmm_impl decides
+  }
+  a.col16 = a.valless && p->col16.ready();
+  if (a.valless && group_pass(p)) {
+    snprintf(buf, (size_t)buflen, "gcn::spmm_group_kernel<%d, %s>", p->group.T, gcn::group_sc1() ? "true" : "false");
+    return GCN_OK;
+  }
+  gcn::describe_main_kernel(a, buf, (size_t)buflen);
+  return GCN_OK;
+}
+
+int gcn_spmm_profile_begin(gcn_spmm_plan_t* p, int32_t capacity) {
+  if (!p || capacity <= 0 || p->prof.capacity() > 0) return GCN_ERR_INVALID_ARG;
+  return p->prof.begin(capacity) == hipSuccess ? GCN_OK : GCN_ERR_HIP;   // (a failed create leaves no events behind)
+}
+
+int gcn_spmm_profile_end(gcn_spmm_plan_t* p, float* ms_out, int32_t* count_out) {
+  if (!p || !count_out || p->prof.capacity() <= 0) return GCN_ERR_INVALID_ARG;
+  int rc = GCN_OK;
+  for (int i = 0; i < p->prof.recorded(); ++i) {
+    float ms = 0.f;
+    if (hipEventSynchronize(p->prof.stop(i)) != hipSuccess ||
+        hipEventElapsedTime(&ms, p->prof.start(i), p->prof.stop(i)) != hipSuccess) rc = GCN_ERR_HIP;
+    if (ms_out) ms_out[i] = ms;
+  }
+  *count_out = p->prof.recorded();
+  p->prof.clear();
+  return rc;
+}
+
+// One-shot: the schedule is recomputed on the device every call (a few µs: one binary search per
+// chunk) into the scratch plan of this (device, stream), so there is no cache that could go stale when
+// the caller reuses device addresses, and calls on different streams or devices never share buffers.
+int gcn_spmm_csr_f32_oneshot(const int32_t* rowptr, const int32_t* col, const float* val,
+                             const float* B, float* C, int32_t m, int32_t n, int32_t nnz,
+                             int32_t k, void* stream) {
+  if (m < 0 || n < 0 || nnz < 0 || k < 0) return GCN_ERR_INVALID_ARG;
+  const int cu = gcn::cu_count_cached();
+  if (cu <= 0) return GCN_ERR_NO_DEVICE;
+  std::lock_guard<std::mutex> lk(g_plan_mu);
+  gcn_spmm_plan* p = gcn::scratch_plan(stream);
+  if (!p) return GCN_ERR_ALLOC;
+  p->m = m; p->n = n; p->nnz = nnz; p->cu_count = cu;
+  p->T = gcn::auto_chunk_nnz(nnz, cu);
+  p->nchunks = (int)(((long long)nnz + p->T - 1) / p->T);
+  if (p->chunk_row.grow((size_t)p->nchunks) != hipSuccess) return GCN_ERR_ALLOC;
+  if (m == 0 || k == 0) return GCN_OK;
+  if (gcn::launch_plan_chunk_rows(rowptr, m, p->T, p->nchunks, p->chunk_row, (hipStream_t)stream) != hipSuccess) return GCN_ERR_HIP;
+  if (p->ws.grow(ws_elems(p, k)) != hipSuccess) return GCN_ERR_ALLOC;
+  gcn::SpmmArgs a;
+  a.rowptr = rowptr; a.col = col; a.val = val; a.B = B; a.C = C; a.P = p->ws;
+  a.chunk_row = p->chunk_row; a.bias = nullptr; a.relu = 0;
+  a.nchunks = p->nchunks; a.T = p->T; a.m = m; a.nnz = nnz; a.k = k; a.n = n;
+  a.nnz_dev = nullptr; a.nchunks_grid = p->nchunks;
+  a.tile_cols = gcn::auto_tile_cols(n, k);
+  return gcn::launch_spmm(a, cu, (hipStream_t)stream) == hipSuccess ? GCN_OK : GCN_ERR_HIP;
+}
+
+int gcn_gather_rows_f32(float* dst, const float* src, const int32_t* idx, int32_t nrows, int32_t k,
+                        void* stream) {
+  if (nrows < 0 || k < 0) return GCN_ERR_INVALID_ARG;
+  if (nrows == 0 || k == 0) return GCN_OK;
+  if (!dst || !src || !idx || dst == src) return GCN_ERR_INVALID_ARG;
+  return gcn::launch_gather_rows(dst, src, idx, nrows, k, (hipStream_t)stream) == hipSuccess
+             ? GCN_OK : GCN_ERR_HIP;
+}
+
+}  // extern "C"

@@ -87,7 +87,7 @@ template <int VEC>
 __global__ void __launch_bounds__(256)
 slice_reduce_kernel(const float* __restrict__ Cv, float* __restrict__ C,
                     const float* __restrict__ bias, int relu, int m, int S, int k, int accumulate,
-                    const float* __restrict__ rowscale) {
+                    const float* __restrict__ rowscale, DropoutSpec drop) {
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int nw = gridDim.x * 4;
@@ -120,6 +120,16 @@ slice_reduce_kernel(const float* __restrict__ Cv, float* __restrict__ C,
       for (int i = 0; i < VEC; ++i) {
         if (bias) acc[i] += bias[x + i];
         if (relu) acc[i] = fmaxf(acc[i], 0.f);
+      }
+      if (drop.on()) {                                  // the dropout mask of the fused epilogue (philox.h)
+        const unsigned long long idx = (unsigned long long)r * (unsigned long long)k + (unsigned long long)x;
+        if (VEC == 4) {
+          const float4 t = dropout_apply4(drop, idx, make_float4(acc[0], acc[1], acc[2], acc[3]));
+          acc[0] = t.x; acc[1] = t.y; acc[2] = t.z; acc[3] = t.w;
+        } else {
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) acc[i] = dropout_apply(drop, idx + i, acc[i]);
+        }
       }
       float* o = C + (size_t)r * (size_t)k + x;
       if (VEC == 4) *reinterpret_cast<float4*>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
@@ -186,13 +196,13 @@ hipError_t build_sliced_csr(const int* rowptr, const int* col, const float* val,
 }
 
 hipError_t launch_slice_reduce(const float* Cv, float* C, const float* bias, int relu, int m, int S,
-                               int k, hipStream_t st, int accumulate, const float* rowscale) {
+                               int k, hipStream_t st, int accumulate, const float* rowscale, const DropoutSpec& drop) {
   if (m <= 0 || k <= 0) return hipSuccess;
   int nb = (m + 3) / 4;
   if (nb > 8192) nb = 8192;
   const uintptr_t al = (uintptr_t)Cv | (uintptr_t)C | (uintptr_t)bias;
-  if (k % 4 == 0 && (al & 15) == 0) slice_reduce_kernel<4><<<nb, 256, 0, st>>>(Cv, C, bias, relu, m, S, k, accumulate, rowscale);
-  else                              slice_reduce_kernel<1><<<nb, 256, 0, st>>>(Cv, C, bias, relu, m, S, k, accumulate, rowscale);
+  if (k % 4 == 0 && (al & 15) == 0) slice_reduce_kernel<4><<<nb, 256, 0, st>>>(Cv, C, bias, relu, m, S, k, accumulate, rowscale, drop);
+  else                              slice_reduce_kernel<1><<<nb, 256, 0, st>>>(Cv, C, bias, relu, m, S, k, accumulate, rowscale, drop);
   return hipGetLastError();
 }
 

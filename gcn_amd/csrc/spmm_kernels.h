@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "philox.h"
 
 namespace gcn {
 
@@ -122,7 +123,10 @@ hipError_t build_sliced_csr(const int* rowptr, const int* col, const float* val,
                             int nnz, int S, int* vrowptr, int* vcol, float* vval,
                             int* sorted_out, hipStream_t st);
 hipError_t launch_slice_reduce(const float* Cv, float* C, const float* bias, int relu, int m, int S,
-                               int k, hipStream_t st, int accumulate = 0, const float* rowscale = nullptr);
+                               int k, hipStream_t st, int accumulate = 0, const float* rowscale = nullptr,
+                               const DropoutSpec& drop = DropoutSpec{});
+// dst[i] = dropout(src[i]) for i < total, mask from the flat index i (dst may be src)
+hipError_t launch_dropout(float* dst, const float* src, long long total, const DropoutSpec& drop, hipStream_t st);
 // values factor as u[r]*u[c]?  u_out[n] (device), *ok_host = 1 when every stored entry matches within 4 ulp
 hipError_t verify_value_factors(const int* rowptr, const int* col, const float* val, const float* u_row,
                                 const float* u_col, int m, int* ok_host, hipStream_t st);

@@ -548,6 +548,29 @@ hipError_t launch_unpad_rows(float* dst, const float* src, const float* bias, in
   return hipGetLastError();
 }
 
+// dst[i] = dropout(src[i]): the mask of the fused epilogue (philox.h) as a pass of its own — used where no
+// epilogue pass exists to carry it (unsliced matrices) and for the backward pass (the same mask on the gradient)
+__global__ void __launch_bounds__(256)
+dropout_kernel(float* __restrict__ dst, const float* __restrict__ src, long long total, DropoutSpec drop, int vec4) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  if (vec4) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i * 4 < total; i += stride)
+      reinterpret_cast<float4*>(dst)[i] = dropout_apply4(drop, (unsigned long long)i * 4, reinterpret_cast<const float4*>(src)[i]);
+  } else {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride)
+      dst[i] = dropout_apply(drop, (unsigned long long)i, src[i]);
+  }
+}
+
+hipError_t launch_dropout(float* dst, const float* src, long long total, const DropoutSpec& drop, hipStream_t st) {
+  if (total <= 0) return hipSuccess;
+  const int vec4 = (total % 4 == 0) && ((((uintptr_t)dst | (uintptr_t)src) & 15) == 0);
+  long long nb = ((vec4 ? total / 4 : total) + 255) / 256;
+  if (nb > 65536) nb = 65536;
+  dropout_kernel<<<(int)nb, 256, 0, st>>>(dst, src, total, drop, vec4);
+  return hipGetLastError();
+}
+
 hipError_t launch_gather_rows(float* dst, const float* src, const int* idx, int nrows, int k,
                               hipStream_t s) {
   if (nrows <= 0 || k <= 0) return hipSuccess;

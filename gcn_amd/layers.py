@@ -22,26 +22,30 @@ import torch.nn.functional as F
 from torch.nn.parameter import Parameter
 
 from . import preprocess, reorder, timers
-from .spmm import CsrAdjacency, _SpmmFunction, gather_rows
+from .spmm import CsrAdjacency, _SpmmFunction, dropout_rows, gather_rows
 
 
 class _FusedSpmmBiasRelu(torch.autograd.Function):
-    """out = relu(Â·X + b) in one kernel; backward through the ReLU mask, Âᵀ and the bias sum."""
+    """out = dropout(relu(Â·X + b)) in one pass over the SpMM output (gcn6.py:141-142, 245-246 as one epilogue);
+    backward through the regenerated dropout mask, the ReLU mask, Âᵀ and the bias sum.  dropout = None or
+    (p, seed, offset)."""
 
     @staticmethod
-    def forward(ctx, adj, x, bias, relu):
-        out = adj.matmul_raw(x, bias=bias, relu=relu)
-        ctx.adj, ctx.relu, ctx.has_bias = adj, relu, bias is not None
+    def forward(ctx, adj, x, bias, relu, dropout=None):
+        out = adj.matmul_raw(x, bias=bias, relu=relu, dropout=dropout)
+        ctx.adj, ctx.relu, ctx.has_bias, ctx.dropout = adj, relu, bias is not None, dropout
         ctx.save_for_backward(out)
         return out
 
     @staticmethod
     def backward(ctx, g):
         (out,) = ctx.saved_tensors
+        if ctx.dropout is not None and ctx.dropout[0] > 0:
+            g = dropout_rows(g, *ctx.dropout)          # the same mask, the same 1/(1-p)
         if ctx.relu:
-            g = g * (out > 0)
+            g = g * (out > 0)                          # (dropped elements are 0 in `out`, and their gradient is 0 already)
         g = g.contiguous()
-        return None, ctx.adj.transpose().matmul_raw(g), (g.sum(0) if ctx.has_bias else None), None
+        return None, ctx.adj.transpose().matmul_raw(g), (g.sum(0) if ctx.has_bias else None), None, None
 
 
 class _Layer(nn.Module):
@@ -72,12 +76,12 @@ class _Layer(nn.Module):
 class GraphConvolution(_Layer):
     """A(XW): support = X·W, output = Â·support (+ bias)  — gcn6.py:99-143."""
 
-    def forward(self, input, adj, relu=False, fuse_epilogue=False):
+    def forward(self, input, adj, relu=False, fuse_epilogue=False, dropout=None):
         with self.timers.hc.xw:
             support = torch.spmm(input, self.weight) if input.is_sparse else torch.mm(input, self.weight)
         if fuse_epilogue:
             with self.timers.hc.af:
-                return _FusedSpmmBiasRelu.apply(adj, support, self.bias, relu)
+                return _FusedSpmmBiasRelu.apply(adj, support, self.bias, relu, dropout)
         with self.timers.hc.af:
             output = _SpmmFunction.apply(adj, support)
         if self.bias is not None:
@@ -128,6 +132,8 @@ class GCN(nn.Module):
         self.fuse_epilogue = fuse_epilogue
         self.output = None
         self.adj = self.features = self.labels = self.vo_mp = None
+        self.tuning = None                    # {slices: ms} measured by prepare() on a renumbered graph
+        self.dropout_seed, self._dropout_calls = 0x5EED, 0
         self.dur_fwd = timers.Timer()
 
     def reset_timing(self):
@@ -137,8 +143,14 @@ class GCN(nn.Module):
 
     def forward(self, x, adj):
         with self.dur_fwd:
-            x = self.gc1(x, adj, relu=self.with_relu, fuse_epilogue=self.fuse_epilogue)
-            x = F.dropout(x, self.dropout, training=self.training)
+            if self.fuse_epilogue and self.training and self.dropout > 0:
+                # bias + ReLU + dropout mask in the SpMM epilogue; a fresh Philox offset per forward pass
+                self._dropout_calls += 1
+                x = self.gc1(x, adj, relu=self.with_relu, fuse_epilogue=True,
+                             dropout=(float(self.dropout), self.dropout_seed, self._dropout_calls))
+            else:
+                x = self.gc1(x, adj, relu=self.with_relu, fuse_epilogue=self.fuse_epilogue)
+                x = F.dropout(x, self.dropout, training=self.training)
             x = self.gc2(x, adj)
             return F.log_softmax(x, dim=1)
 
@@ -170,6 +182,12 @@ class GCN(nn.Module):
             rp, ci, va, vo_mp = (torch.from_numpy(x).to(dev) for x in (rp, ci, va, vo_mp))
         n = rp.numel() - 1
         self.adj = CsrAdjacency(rp, ci, va, (n, n), symmetric=True)             # steps 2+3
+        if self.order:
+            # A renumbered graph may sit near its diagonal (Rabbit / RCM / Gorder on a graph with communities):
+            # the XCD-contiguous chunk ranges then already keep neighbours in one L2 and the column slicing the
+            # automatic rule picks for UNORDERED graphs of this size can lose to the plain pass (planted
+            # partition, n = 60 k, Rabbit: 0.55 ms unsliced, 0.73 ms sliced).  Measure once, keep the faster.
+            self.tuning = self.adj.autotune(k=max(self.hidden_sizes[0], 64))
         self.vo_mp = vo_mp
         self.features = gather_rows(features.to(dev), self.vo_mp)                # step 4
         self.labels = torch.as_tensor(np.asarray(labels), dtype=torch.int64).to(dev)[self.vo_mp.long()]

@@ -238,8 +238,10 @@ class CsrAdjacency:
         return self._transpose
 
     # -- the op ------------------------------------------------------------------
-    def matmul_raw(self, dense, out=None, bias=None, relu=False):
-        """C = Â·dense (+bias, ReLU) with no autograd; dense is [n x k] fp32 on the same device."""
+    def matmul_raw(self, dense, out=None, bias=None, relu=False, dropout=None):
+        """C = dropout(act(Â·dense + bias)) with no autograd; dense is [n x k] fp32 on the same device.
+        dropout = (p, seed, offset): the mask of gcn_spmm_csr_f32_epilogue (element i kept iff its Philox word
+        passes; kept values scaled by 1/(1-p)); `dropout_rows` applies the same mask to a gradient."""
         if not dense.is_cuda or dense.dtype != torch.float32 or dense.dim() != 2:
             raise _lib.GcnAmdError("dense operand must be a 2-D fp32 CUDA/HIP tensor")
         if dense.shape[0] != self.n:
@@ -252,7 +254,12 @@ class CsrAdjacency:
             raise ValueError("out must be a contiguous fp32 [m x k] tensor")
         lib = _lib.load()
         with torch.cuda.device(self.device):
-            if bias is None and not relu:
+            if dropout is not None and float(dropout[0]) > 0.0:
+                bp = _ptr(bias.contiguous()) if bias is not None else ctypes.c_void_p()
+                st = lib.gcn_spmm_csr_f32_epilogue(self.plan, _ptr(self.rowptr), _ptr(self.col), _ptr(self.val),
+                                                   _ptr(dense), _ptr(out), bp, 1 if relu else 0, float(dropout[0]),
+                                                   int(dropout[1]), int(dropout[2]), k, _stream_ptr(self.device))
+            elif bias is None and not relu:
                 st = lib.gcn_spmm_csr_f32(self.plan, _ptr(self.rowptr), _ptr(self.col), _ptr(self.val),
                                           _ptr(dense), _ptr(out), k, _stream_ptr(self.device))
             else:
@@ -359,4 +366,20 @@ def gather_rows(src, idx, out=None):
         st = _lib.load().gcn_gather_rows_f32(_ptr(out), _ptr(src), _ptr(idx), nrows, k,
                                              _stream_ptr(src.device))
     _lib.check(st, "gcn_gather_rows_f32")
+    return out
+
+
+def dropout_rows(x, p, seed, offset, out=None):
+    """out = x with the dropout mask of the fused epilogue (gcn_dropout_f32): element i of the contiguous fp32 tensor
+    is kept (and scaled by 1/(1-p)) iff its Philox4x32-10 word passes — the same function of (seed, offset, i) the
+    SpMM epilogue uses, so applying it to a gradient is the backward of that epilogue."""
+    if not x.is_cuda or x.dtype != torch.float32:
+        raise _lib.GcnAmdError("dropout_rows needs an fp32 CUDA/HIP tensor")
+    x = x.contiguous()
+    if out is None:
+        out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        st = _lib.load().gcn_dropout_f32(_ptr(out), _ptr(x), int(x.numel()), float(p), int(seed), int(offset),
+                                         _stream_ptr(x.device))
+    _lib.check(st, "gcn_dropout_f32")
     return out

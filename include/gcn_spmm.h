@@ -54,7 +54,7 @@ typedef struct gcn_spmm_plan gcn_spmm_plan_t;
 
 /* Build the per-graph schedule (equal-nnz chunks + first row of each chunk) on
  * the device.  `rowptr_dev` is the int32 CSR row pointer [m+1] in device memory;
- * it is only read during this call.  `chunk_nnz` = 0 picks a size automatically
+ * it is only read during this call (the call synchronises `stream` before it returns).  `chunk_nnz` = 0 picks a size automatically
  * (multiple of 64).  The plan owns a small device buffer and a grow-only
  * workspace for the partial sums of rows that straddle chunk boundaries. */
 int gcn_spmm_plan_create(gcn_spmm_plan_t** plan, const int32_t* rowptr_dev,
@@ -84,6 +84,24 @@ int gcn_spmm_csr_f32_bias_relu(gcn_spmm_plan_t* plan,
                      const float* val_dev, const float* B_dev, float* C_dev,
                      const float* bias_dev, int32_t relu,
                      int32_t k, void* stream);
+
+/* The full fused epilogue of a GCN layer (pygcn/gcn6.py:141-142, 245-246: bias add, ReLU and
+ * dropout are three separate PyTorch ops there):  C = dropout(act(A*B + bias)).  dropout_p in [0, 1) is the drop
+ * probability (0 = none); kept elements are scaled by 1/(1-p).  The mask is NOT stored: element i = r*k + c is kept
+ * iff word (i mod 4) of Philox4x32-10(counter = (i / 4, offset), key = seed) >= p * 2^32, so the backward pass
+ * regenerates it with gcn_dropout_f32 on the gradient (same p, seed, offset) and every kernel family agrees.  Where
+ * the plan has an epilogue pass (column slicing: the slice reduction) the mask rides in it; otherwise one in-place
+ * pass over C applies it.  (torch's own dropout stream cannot be reproduced: the semantic — Bernoulli(1-p), scaled
+ * — is what is matched.) */
+int gcn_spmm_csr_f32_epilogue(gcn_spmm_plan_t* plan,
+                     const int32_t* rowptr_dev, const int32_t* col_dev,
+                     const float* val_dev, const float* B_dev, float* C_dev,
+                     const float* bias_dev, int32_t relu, float dropout_p, uint64_t seed, uint64_t offset,
+                     int32_t k, void* stream);
+/* dst[i] = dropout(src[i]) for i < count with the mask defined above (dst may equal src): the backward of the
+ * fused epilogue, and the forward where no fused pass exists. */
+int gcn_dropout_f32(float* dst_dev, const float* src_dev, int64_t count, float dropout_p, uint64_t seed,
+                    uint64_t offset, void* stream);
 
 /* Feature-column tile per kernel pass: 0 = automatic, else 64, 128 or 256 columns.  A k-wide
  * SpMM runs as ceil(k/tile) back-to-back passes, each gathering only its column slice of B
@@ -160,8 +178,9 @@ double gcn_spmm_plan_panel_coverage(const gcn_spmm_plan_t* plan);    /* fraction
 int gcn_spmm_profile_begin(gcn_spmm_plan_t* plan, int32_t capacity);
 int gcn_spmm_profile_end(gcn_spmm_plan_t* plan, float* ms_out, int32_t* count_out);
 
-/* One-shot convenience with an internal plan cache keyed on (rowptr_dev, m, nnz);
- * this is the body of the drop-in `cuspmm` symbol. */
+/* One-shot convenience: the schedule is rebuilt on the device at every call into scratch buffers that belong to
+ * the calling (device, stream) pair, so concurrent calls on different streams or devices never share state.
+ * This is the body of the drop-in `cuspmm` symbol. */
 int gcn_spmm_csr_f32_oneshot(const int32_t* rowptr_dev, const int32_t* col_dev,
                      const float* val_dev, const float* B_dev, float* C_dev,
                      int32_t m, int32_t n, int32_t nnz, int32_t k, void* stream);

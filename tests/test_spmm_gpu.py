@@ -504,7 +504,8 @@ def test_rccl_collectives_used_by_the_multi_gpu_path_single_rank():
         buf_in, buf_out = sh.to_padded(H), sh.new_buffer(k, d)
         slot = buf_out[0: sh.max_rows]
         sh.local.matmul_raw(buf_in, out=slot[: sh.rows])
-        work = sh._all_gather(buf_out, slot, None, True)          # the in-place async all-gather
+        assert sh.collective_form() == "none"                     # (one rank: layer() would not exchange at all)
+        work = sh._exchange(buf_out, slot, None, True)            # the in-place async all-gather, as RCCL runs it
         work.wait()
         dist.barrier()
         tmax = torch.tensor([1.5], dtype=torch.float64, device=d)
