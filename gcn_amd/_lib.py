@@ -45,6 +45,7 @@ SIGNATURES = {
     "gcn_spmm_plan_enable_panels": (ctypes.c_int, [_c_p, _c_p, _c_p, _c_p, _c_i32, _c_p]),
     "gcn_spmm_plan_panel_rows": (_c_i32, [_c_p]),
     "gcn_spmm_plan_panel_coverage": (ctypes.c_double, [_c_p]),
+    "gcn_spmm_plan_dense_panels": (_c_i32, [_c_p]),
     "gcn_spmm_profile_begin": (ctypes.c_int, [_c_p, _c_i32]),
     "gcn_spmm_profile_end": (ctypes.c_int, [_c_p, _c_p, _c_p]),
     "gcn_spmm_csr_f32_oneshot": (ctypes.c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_i32, _c_i32, _c_i32, _c_i32, _c_p]),

@@ -70,6 +70,12 @@ int group_chunk() {                                                             
   static const int v = [] { const int t = env_int("GCN_AMD_GROUP_T", 512); return (t == 256 || t == 512 || t == 1024 || t == 2048) ? t : 512; }();
   return v;
 }
+bool panel_mfma_enabled() { static const bool v = env_on("GCN_AMD_PANEL_MFMA"); return v; }   // dense panels on the matrix cores
+double panel_mfma_density() {                                                              // ... from this window density up
+  static const double v = [] { const char* e = std::getenv("GCN_AMD_PANEL_MFMA_DENSITY"); const double d = e ? std::atof(e) : 0.25;
+                               return d > 0.0 && d <= 1.0 ? d : 0.25; }();
+  return v;
+}
 int slice_min_k() { static const int v = env_int("GCN_AMD_SLICE_MIN_K", 33); return v; }  // smallest k the sliced copy is used for
 
 // Expected 128-byte cache lines one gathered feature row costs, summed over its 64-column tiles, when B's
@@ -285,9 +291,12 @@ int spmm_impl(gcn_spmm_plan* p, const int32_t* rowptr, const int32_t* col, const
     // chunk kernel, which also carries the epilogue
     if (ev0 && hipEventRecord(ev0, st) != hipSuccess) return GCN_ERR_HIP;
     const int tiles = (k + 63) / 64;
-    for (int t = 0; t < tiles; ++t)
-      if (gcn::launch_panel_in(pn.in_rowptr, pn.in_off, pn.in_val, B, C, pn.w0, p->m, p->n, k, pn.R, t, st) != hipSuccess)
+    for (int t = 0; t < tiles; ++t) {
+      if (gcn::launch_panel_in(pn.in_rowptr, pn.in_off, pn.in_val, B, C, pn.w0, p->m, p->n, k, pn.R, t, st, pn.dense_slot) != hipSuccess)
         return GCN_ERR_HIP;
+      if (gcn::launch_panel_dense(pn.adense, pn.dense_panel, pn.ndense, B, C, pn.w0, p->m, p->n, k, pn.R, t, st) != hipSuccess)
+        return GCN_ERR_HIP;
+    }
     if (pn.out_nnz == 0) {
       if (gcn::launch_panel_epilogue(C, bias, relu, p->m, k, st) != hipSuccess) return GCN_ERR_HIP;
       if (ev1 && hipEventRecord(ev1, st) != hipSuccess) return GCN_ERR_HIP;
@@ -592,25 +601,53 @@ int gcn_spmm_plan_enable_panels(gcn_spmm_plan_t* p, const int32_t* rowptr, const
   const int npanels = (p->m + R - 1) / R;
   hipStream_t st = (hipStream_t)stream;
   gcn::Panels pn;
-  if (pn.w0.alloc((size_t)npanels) != hipSuccess) return GCN_ERR_ALLOC;
+  gcn::DevBuf<int> pcnt;                               // in-window non-zeros of every panel
+  if (pn.w0.alloc((size_t)npanels) != hipSuccess || pcnt.alloc((size_t)npanels) != hipSuccess) return GCN_ERR_ALLOC;
   unsigned long long inside = 0;
-  if (gcn::panel_plan(rowptr, col, p->m, p->n, R, pn.w0, &inside, st) != hipSuccess) return GCN_ERR_HIP;
+  if (gcn::panel_plan(rowptr, col, p->m, p->n, R, pn.w0, &inside, st, pcnt) != hipSuccess) return GCN_ERR_HIP;
   pn.coverage = (double)inside / (double)p->nnz;
   // automatic: only when at least half of the non-zeros are served from the staged tile
   if (!(mode == 1 || pn.coverage >= 0.5)) { p->panels.coverage = pn.coverage; return GCN_OK; }
-  // split A = A_in + A_out on the device
+  // Panels whose 128 x 512 window is dense enough leave the sparse formats altogether: a dense fp32 tile in
+  // MFMA fragment order, contracted on the matrix cores (spmm_panel_dense_mfma_kernel); break-even against one
+  // LDS read per entry is near 13 % density, the default threshold 25 %.
+  if (gcn::panel_mfma_enabled()) {
+    std::vector<int> cnt((size_t)npanels), slot((size_t)npanels, -1), ids;
+    if (hipMemcpyAsync(cnt.data(), pcnt, sizeof(int) * (size_t)npanels, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess)
+      return GCN_ERR_HIP;
+    const double thr = gcn::panel_mfma_density() * (double)R * 512.0;
+    for (int q = 0; q < npanels; ++q)
+      if ((double)cnt[(size_t)q] >= thr) { slot[(size_t)q] = (int)ids.size(); ids.push_back(q); }
+    if (!ids.empty()) {
+      const size_t tile = (size_t)R * 512;
+      if (pn.dense_slot.alloc((size_t)npanels) != hipSuccess || pn.dense_panel.alloc(ids.size()) != hipSuccess ||
+          pn.adense.alloc(ids.size() * tile) != hipSuccess)
+        return GCN_ERR_ALLOC;
+      if (hipMemcpyAsync(pn.dense_slot, slot.data(), sizeof(int) * (size_t)npanels, hipMemcpyHostToDevice, st) != hipSuccess ||
+          hipMemcpyAsync(pn.dense_panel, ids.data(), sizeof(int) * ids.size(), hipMemcpyHostToDevice, st) != hipSuccess ||
+          hipMemsetAsync(pn.adense, 0, sizeof(float) * ids.size() * tile, st) != hipSuccess ||
+          hipStreamSynchronize(st) != hipSuccess)               // (slot / ids are host vectors)
+        return GCN_ERR_HIP;
+      pn.ndense = (int)ids.size();
+    }
+  }
+  // split A = A_in + A_out (+ the dense tiles) on the device
   if (pn.in_rowptr.alloc((size_t)p->m + 1) != hipSuccess || pn.out_rowptr.alloc((size_t)p->m + 1) != hipSuccess)
     return GCN_ERR_ALLOC;
   int nnz_in = 0;
   if (gcn::panel_split(rowptr, col, val, pn.w0, p->m, R, pn.in_rowptr, pn.out_rowptr, nullptr, nullptr, nullptr, nullptr,
-                       &nnz_in, st) != hipSuccess)
+                       &nnz_in, st, pn.dense_slot) != hipSuccess)
     return GCN_ERR_HIP;
-  const int nnz_out = p->nnz - nnz_in;
+  int nnz_out = 0;                                     // (dense-tile entries are neither staged nor rest)
+  if (hipMemcpyAsync(&nnz_out, pn.out_rowptr + p->m, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
+      hipStreamSynchronize(st) != hipSuccess)
+    return GCN_ERR_HIP;
   if (pn.in_off.alloc((size_t)nnz_in) != hipSuccess || pn.in_val.alloc((size_t)nnz_in) != hipSuccess ||
       pn.out_col.alloc((size_t)nnz_out) != hipSuccess || pn.out_val.alloc((size_t)nnz_out) != hipSuccess)
     return GCN_ERR_ALLOC;
   if (gcn::panel_split(rowptr, col, val, pn.w0, p->m, R, pn.in_rowptr, pn.out_rowptr, pn.in_off, pn.in_val, pn.out_col,
-                       pn.out_val, &nnz_in, st) != hipSuccess)
+                       pn.out_val, &nnz_in, st, pn.dense_slot, pn.adense) != hipSuccess)
     return GCN_ERR_HIP;
   pn.out_nnz = nnz_out;
   pn.out_T = gcn::auto_chunk_nnz(nnz_out, p->cu_count);
@@ -648,6 +685,7 @@ int gcn_spmm_plan_enable_panels(gcn_spmm_plan_t* p, const int32_t* rowptr, const
 }
 
 int32_t gcn_spmm_plan_panel_rows(const gcn_spmm_plan_t* p) { return p ? p->panels.R : -1; }
+int32_t gcn_spmm_plan_dense_panels(const gcn_spmm_plan_t* p) { return p ? p->panels.ndense : -1; }
 double gcn_spmm_plan_panel_coverage(const gcn_spmm_plan_t* p) { return p ? p->panels.coverage : -1.0; }
 
 int gcn_spmm_plan_set_tile_cols(gcn_spmm_plan_t* p, int32_t cols) {

@@ -129,6 +129,10 @@ struct Panels {
   int out_S = 0;                                    // column slices of the out-of-window part (0: unsliced)
   DevBuf<int> out_vrowptr, out_vcol, out_vchunk_row;
   DevBuf<float> out_vval;
+  // dense panels on the matrix cores (spmm_panel_dense_mfma_kernel)
+  int ndense = 0;
+  DevBuf<int> dense_slot, dense_panel;              // [panels]: slot or -1; [ndense]: panel of every slot
+  DevBuf<float> adense;                             // [ndense x 128 x 512] in MFMA fragment order
 };
 
 }  // namespace gcn

@@ -94,14 +94,20 @@ hipError_t launch_scale_rows_sliced(float* dst, const float* src, const float* r
                                     int S, int w, hipStream_t s);
 
 // spmm_panel.hip — LDS-staged feature tiles per row panel (near-diagonal matrices)
+// cnt_dev (optional, [panels]): in-window non-zeros of every panel
 hipError_t panel_plan(const int* rowptr, const int* col, int m, int n, int R, int* w0_dev,
-                      unsigned long long* inside_host, hipStream_t st);
+                      unsigned long long* inside_host, hipStream_t st, int* cnt_dev = nullptr);
+// dense_slot (optional, [panels]): slot of the panel's dense tile, -1 for an ordinary panel; the in-window entries of
+// dense panels go into `adense` (MFMA fragment order, 128 x 512 floats per slot, zeroed by the caller) instead
 hipError_t panel_split(const int* rowptr, const int* col, const float* val, const int* w0_dev, int m,
                        int R, int* in_rowptr, int* out_rowptr, int* in_off, float* in_val,
-                       int* out_col, float* out_val, int* nnz_in_host, hipStream_t st);
+                       int* out_col, float* out_val, int* nnz_in_host, hipStream_t st,
+                       const int* dense_slot = nullptr, float* adense = nullptr);
 hipError_t launch_panel_in(const int* in_rowptr, const int* in_off, const float* in_val, const float* B,
                            float* C, const int* panel_w0, int m, int n, int k, int R, int tile,
-                           hipStream_t s);
+                           hipStream_t s, const int* dense_slot = nullptr);
+hipError_t launch_panel_dense(const float* adense, const int* dense_panel, int ndense, const float* B, float* C,
+                              const int* panel_w0, int m, int n, int k, int R, int tile, hipStream_t s);
 hipError_t launch_panel_epilogue(float* C, const float* bias, int relu, int m, int k, hipStream_t s);
 
 // reorder_device.hip — degree / RCM orderings and the CSR rewrite on the device (same integers as reorder.cpp)

@@ -51,7 +51,7 @@ __device__ __host__ __forceinline__ int panel_diag_window(int r0, int R, int m, 
 // best run of 4 bins -> w0[panel]; adds the covered non-zeros to *inside.
 __global__ void __launch_bounds__(256)
 panel_windows_kernel(const int* __restrict__ rowptr, const int* __restrict__ col, int m, int n, int R,
-                     int* __restrict__ w0_out, unsigned long long* __restrict__ inside) {
+                     int* __restrict__ w0_out, unsigned long long* __restrict__ inside, int* __restrict__ cnt_out) {
   __shared__ unsigned int hist[PANEL_MAX_BINS];
   __shared__ int best_w0;
   __shared__ unsigned int best_cnt;
@@ -91,6 +91,7 @@ panel_windows_kernel(const int* __restrict__ rowptr, const int* __restrict__ col
   __syncthreads();
   if (threadIdx.x == 0) {
     w0_out[p] = w0;
+    if (cnt_out) cnt_out[p] = (int)best_cnt;
     if (best_cnt) atomicAdd(inside, (unsigned long long)best_cnt);
   }
 }
@@ -98,7 +99,7 @@ panel_windows_kernel(const int* __restrict__ rowptr, const int* __restrict__ col
 // plan time: per-row count of staged (in-window) entries; one wave per row
 __global__ void __launch_bounds__(256)
 panel_split_count_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
-                         const int* __restrict__ panel_w0, int m, int R,
+                         const int* __restrict__ panel_w0, const int* __restrict__ dense_slot, int m, int R,
                          int* __restrict__ cnt_in, int* __restrict__ cnt_out) {
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -109,7 +110,8 @@ panel_split_count_kernel(const int* __restrict__ rowptr, const int* __restrict__
     int c = 0;
     for (int e = beg + lane; e < end; e += 64) c += (unsigned)(col[e] - w0) < (unsigned)PANEL_W;
     for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
-    if (lane == 0) { cnt_in[r] = c; cnt_out[r] = end - beg - c; }
+    // (a dense panel's in-window entries live in its dense tile: neither staged part nor rest)
+    if (lane == 0) { cnt_in[r] = (dense_slot && dense_slot[r / R] >= 0) ? 0 : c; cnt_out[r] = end - beg - c; }
   }
 }
 
@@ -118,26 +120,33 @@ panel_split_count_kernel(const int* __restrict__ rowptr, const int* __restrict__
 __global__ void __launch_bounds__(256)
 panel_split_scatter_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
                            const float* __restrict__ val, const int* __restrict__ panel_w0,
+                           const int* __restrict__ dense_slot,
                            const int* __restrict__ in_rowptr, const int* __restrict__ out_rowptr,
                            int m, int R, int* __restrict__ in_off, float* __restrict__ in_val,
-                           int* __restrict__ out_col, float* __restrict__ out_val) {
+                           int* __restrict__ out_col, float* __restrict__ out_val, float* __restrict__ adense) {
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int nw = gridDim.x * 4;
   for (int r = wave; r < m; r += nw) {
     const int w0 = panel_w0[r / R];
+    const int slot = dense_slot ? dense_slot[r / R] : -1;
     const int beg = rowptr[r], end = rowptr[r + 1];
     int pin = in_rowptr[r], pout = out_rowptr[r];
     for (int base = beg; base < end; base += 64) {
       const bool valid = base + lane < end;
       const int c = valid ? col[base + lane] : 0;
       const float v = valid ? val[base + lane] : 0.f;
-      const bool in = valid && (unsigned)(c - w0) < (unsigned)PANEL_W;
-      const unsigned long long mi = __ballot(in), mo = __ballot(valid && !in);
+      const bool inwin = valid && (unsigned)(c - w0) < (unsigned)PANEL_W;
+      const bool in = inwin && slot < 0;              // staged entry of an ordinary panel
+      if (inwin && slot >= 0) {                       // dense panel: straight into its MFMA fragment image
+        const int i = r - (r / R) * R, kk = c - w0;   // A[i][kk] of the panel -> row block i/32, k-step kk/2, lane (kk&1)*32 + i%32
+        adense[(((size_t)slot * 4 + (i >> 5)) * (PANEL_W / 2) + (kk >> 1)) * 64 + (kk & 1) * 32 + (i & 31)] = v;
+      }
+      const unsigned long long mi = __ballot(in), mo = __ballot(valid && !inwin);
       const int ri = __builtin_amdgcn_mbcnt_hi((unsigned)(mi >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mi, 0));
       const int ro = __builtin_amdgcn_mbcnt_hi((unsigned)(mo >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mo, 0));
       if (in) { in_off[pin + ri] = (c - w0) * 256; in_val[pin + ri] = v; }
-      else if (valid) { out_col[pout + ro] = c; out_val[pout + ro] = v; }
+      else if (valid && !inwin) { out_col[pout + ro] = c; out_val[pout + ro] = v; }
       pin += __builtin_popcountll(mi);
       pout += __builtin_popcountll(mo);
     }
@@ -146,11 +155,12 @@ panel_split_scatter_kernel(const int* __restrict__ rowptr, const int* __restrict
 
 // run time: C[r, tile] = sum over the staged entries of row r, from LDS only
 __global__ void __launch_bounds__(PANEL_WAVES * 64)
-spmm_panel_in_kernel(const int* __restrict__ in_rowptr, const int* __restrict__ in_off,
+spmm_panel_in_kernel(const int* __restrict__ dense_slot, const int* __restrict__ in_rowptr, const int* __restrict__ in_off,
                      const float* __restrict__ in_val, const float* __restrict__ B,
                      float* __restrict__ C, const int* __restrict__ panel_w0,
                      int m, int n, int k, int R, int col_tile) {
   extern __shared__ float lds[];                    // [PANEL_W][64] tile + [PANEL_WAVES][64] scratch
+  if (dense_slot && dense_slot[blockIdx.x] >= 0) return;       // a dense panel: spmm_panel_dense_mfma_kernel owns it
   const char* tile = reinterpret_cast<const char*>(lds);
   float* scratch = lds + PANEL_W * 64;
   const int tid = threadIdx.x;
@@ -251,11 +261,12 @@ __device__ __forceinline__ int panel_bcast(int v) {
 }
 
 __global__ void __launch_bounds__(PANEL_WAVES * 64)
-spmm_panel_in_quad_kernel(const int* __restrict__ in_rowptr, const int* __restrict__ in_off,
+spmm_panel_in_quad_kernel(const int* __restrict__ dense_slot, const int* __restrict__ in_rowptr, const int* __restrict__ in_off,
                           const float* __restrict__ in_val, const float* __restrict__ B,
                           float* __restrict__ C, const int* __restrict__ panel_w0,
                           int m, int n, int k, int R, int col_tile) {
   extern __shared__ float lds[];                    // [PANEL_W][64] tile + [PANEL_WAVES][16] float4 scratch
+  if (dense_slot && dense_slot[blockIdx.x] >= 0) return;       // a dense panel: spmm_panel_dense_mfma_kernel owns it
   const char* tile = reinterpret_cast<const char*>(lds);
   float4* scratch = reinterpret_cast<float4*>(lds + PANEL_W * 64);
   const int tid = threadIdx.x;
@@ -358,6 +369,98 @@ spmm_panel_in_quad_kernel(const int* __restrict__ in_rowptr, const int* __restri
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Dense panels on the matrix cores (BASELINE north_star: "MFMA used only on the dense row-panel x feature-tile
+// inner product where nnz-per-panel actually forms a dense contraction").  A panel whose 128 x 512 window is
+// dense enough is stored at plan time as a DENSE fp32 tile in MFMA fragment order (256 KiB: above ~50 % density
+// smaller than its CSR), and its staged product  C[128 x 64] = A[128 x 512] * Bwin[512 x 64]  runs as 8 waves x
+// 256 v_mfma_f32_32x32x2_f32 — exact fp32 (a k-ordered fma chain, cdna_hip_programming.md §3), so parity-safe:
+// wave (ib, nb) owns the 32 x 32 block (rows 32 ib .., columns 32 nb ..), its A fragment of k-step j is one
+// coalesced 256-byte load (lane l = A[32 ib + l%32][2 j + l/32]), its B fragment one conflict-free ds_read_b32
+// of the staged window.  32.8 k cycles per panel and tile whatever the density, against one LDS read per ENTRY
+// in the kernels above: break-even near 13 % density, 5x at 70 %.
+// A dense contraction multiplies the zeros of A too, and 0 * Inf = NaN would leak a non-finite feature row into
+// rows of A that do not reference it; the staging pass therefore looks for non-finite values and, if the window
+// holds any, the workgroup sums its rows entry by entry from the dense tile (skipping zeros) instead.
+// ---------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int MFMA_WAVES = 8;
+
+__global__ void __launch_bounds__(MFMA_WAVES * 64)
+spmm_panel_dense_mfma_kernel(const float* __restrict__ adense, const int* __restrict__ dense_panel,
+                             const float* __restrict__ B, float* __restrict__ C, const int* __restrict__ panel_w0,
+                             int m, int n, int k, int R, int col_tile) {
+  extern __shared__ float lds[];                    // [PANEL_W][64] window tile
+  __shared__ int nonfinite;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = psgpr(tid >> 6);
+  const int pd = blockIdx.x;
+  const int p = dense_panel[pd];
+  const int r0 = p * R, r1 = min(m, r0 + R);
+  const int w0 = panel_w0[p];
+  const int wn = min(PANEL_W, n - w0);
+  const size_t kk = (size_t)k;
+  if (tid == 0) nonfinite = 0;
+  __syncthreads();
+  // ---- stage the window's feature tile; rows past the matrix edge and columns past k are zero ----
+  bool bad = false;
+  for (int i0 = tid; i0 < PANEL_W * 64; i0 += MFMA_WAVES * 64 * 8) {
+    float t[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int i = i0 + q * MFMA_WAVES * 64;
+      const int rr = i >> 6, cc = col_tile * 64 + (i & 63);
+      t[q] = (i < wn * 64 && cc < k) ? B[(size_t)(w0 + rr) * kk + cc] : 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int i = i0 + q * MFMA_WAVES * 64;
+      if (i < PANEL_W * 64) { lds[i] = t[q]; bad |= !(fabsf(t[q]) <= 3.402823466e+38f); }
+    }
+  }
+  if (bad) nonfinite = 1;
+  __syncthreads();
+  const float* __restrict__ Ap = adense + (size_t)pd * 4 * (PANEL_W / 2) * 64;      // this panel's fragment image
+  if (!nonfinite) {
+    const int ib = w >> 1, nb = w & 1;              // this wave's 32 x 32 block of the 128 x 64 result
+    const float* __restrict__ Af = Ap + (size_t)ib * (PANEL_W / 2) * 64 + lane;
+    const float* __restrict__ Bl = lds + (lane >> 5) * 64 + nb * 32 + (lane & 31);   // B[k = 2 j + lane/32][col]
+    f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    float a[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a[u] = Af[(size_t)u * 64];
+    for (int j0 = 0; j0 < PANEL_W / 2; j0 += 8) {   // A fragments are fetched eight k-steps ahead
+      float an[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) an[u] = j0 + 8 + u < PANEL_W / 2 ? Af[(size_t)(j0 + 8 + u) * 64] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], Bl[(j0 + u) * 128], acc, 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] = an[u];
+    }
+    // C/D layout of the 32x32 forms: column = lane % 32, row = (reg % 4) + 8 (reg / 4) + 4 (lane / 32)
+    const int c = col_tile * 64 + nb * 32 + (lane & 31);
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const int r = r0 + ib * 32 + (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5);
+      if (r < r1 && c < k) C[(size_t)r * kk + c] = acc[v];
+    }
+    return;
+  }
+  // ---- a non-finite feature value inside the window: entry by entry, zeros of A skipped (rare; slow is fine) ----
+  const int c = col_tile * 64 + lane;
+  for (int i = w; i < R && r0 + i < r1; i += MFMA_WAVES) {
+    const float* __restrict__ Ai = Ap + (size_t)(i >> 5) * (PANEL_W / 2) * 64 + (i & 31);
+    float acc = 0.f;
+    for (int q = 0; q < PANEL_W; ++q) {
+      const float av = Ai[(size_t)(q >> 1) * 64 + (q & 1) * 32];                    // A[i][q] (wave-uniform)
+      if (av != 0.f) acc = fmaf(av, lds[q * 64 + lane], acc);
+    }
+    if (c < k) C[(size_t)(r0 + i) * kk + c] = acc;
+  }
+}
+
 // C = act(C + bias): the epilogue alone, for when the out-of-window part is empty
 __global__ void panel_epilogue_kernel(float* __restrict__ C, const float* __restrict__ bias, int relu,
                                       long long total, int k) {
@@ -373,7 +476,7 @@ __global__ void panel_epilogue_kernel(float* __restrict__ C, const float* __rest
 // ---------------------------------------------------------------------------------------------
 // plan time: choose the windows (device array w0_dev[npanels], caller-allocated) and measure coverage
 hipError_t panel_plan(const int* rowptr, const int* col, int m, int n, int R, int* w0_dev,
-                      unsigned long long* inside_host, hipStream_t st) {
+                      unsigned long long* inside_host, hipStream_t st, int* cnt_dev) {
   *inside_host = 0;
   if (m <= 0) return hipSuccess;
   unsigned long long* d_inside = nullptr;
@@ -381,7 +484,7 @@ hipError_t panel_plan(const int* rowptr, const int* col, int m, int n, int R, in
   if ((e = hipMalloc((void**)&d_inside, sizeof(unsigned long long))) != hipSuccess) return e;
   (void)hipMemsetAsync(d_inside, 0, sizeof(unsigned long long), st);
   const int panels = (m + R - 1) / R;
-  panel_windows_kernel<<<panels, 256, 0, st>>>(rowptr, col, m, n, R, w0_dev, d_inside);
+  panel_windows_kernel<<<panels, 256, 0, st>>>(rowptr, col, m, n, R, w0_dev, d_inside, cnt_dev);
   e = hipGetLastError();
   if (e == hipSuccess) e = hipMemcpyAsync(inside_host, d_inside, sizeof(unsigned long long), hipMemcpyDeviceToHost, st);
   if (e == hipSuccess) e = hipStreamSynchronize(st);
@@ -394,7 +497,8 @@ hipError_t panel_plan(const int* rowptr, const int* col, int m, int n, int R, in
 // the row pointers and *nnz_in_host; pass 2 scatters the entries.
 hipError_t panel_split(const int* rowptr, const int* col, const float* val, const int* w0_dev, int m,
                        int R, int* in_rowptr, int* out_rowptr, int* in_off, float* in_val,
-                       int* out_col, float* out_val, int* nnz_in_host, hipStream_t st) {
+                       int* out_col, float* out_val, int* nnz_in_host, hipStream_t st,
+                       const int* dense_slot, float* adense) {
   hipError_t e = hipSuccess;
   int nb = (m + 3) / 4;
   if (nb > 16384) nb = 16384;
@@ -412,7 +516,7 @@ hipError_t panel_split(const int* rowptr, const int* col, const float* val, cons
     if ((e = hipMalloc((void**)&co, sizeof(int) * (size_t)(m + 1))) != hipSuccess) return done(e);
     (void)hipMemsetAsync(ci + m, 0, sizeof(int), st);
     (void)hipMemsetAsync(co + m, 0, sizeof(int), st);
-    panel_split_count_kernel<<<nb, 256, 0, st>>>(rowptr, col, w0_dev, m, R, ci, co);
+    panel_split_count_kernel<<<nb, 256, 0, st>>>(rowptr, col, w0_dev, dense_slot, m, R, ci, co);
     if ((e = hipGetLastError()) != hipSuccess) return done(e);
     if ((e = hipcub::DeviceScan::ExclusiveSum(nullptr, tb, ci, in_rowptr, m + 1, st)) != hipSuccess) return done(e);
     if ((e = hipcub::DeviceScan::ExclusiveSum(nullptr, tb2, co, out_rowptr, m + 1, st)) != hipSuccess) return done(e);
@@ -423,8 +527,8 @@ hipError_t panel_split(const int* rowptr, const int* col, const float* val, cons
     if ((e = hipMemcpyAsync(nnz_in_host, in_rowptr + m, sizeof(int), hipMemcpyDeviceToHost, st)) != hipSuccess) return done(e);
     return done(hipStreamSynchronize(st));
   }
-  panel_split_scatter_kernel<<<nb, 256, 0, st>>>(rowptr, col, val, w0_dev, in_rowptr, out_rowptr, m, R,
-                                                 in_off, in_val, out_col, out_val);
+  panel_split_scatter_kernel<<<nb, 256, 0, st>>>(rowptr, col, val, w0_dev, dense_slot, in_rowptr, out_rowptr, m, R,
+                                                 in_off, in_val, out_col, out_val, adense);
   if ((e = hipGetLastError()) != hipSuccess) return e;
   return hipStreamSynchronize(st);
 }
@@ -432,7 +536,7 @@ hipError_t panel_split(const int* rowptr, const int* col, const float* val, cons
 // staged part: C[:, tile] = A_in * B[:, tile] for one 64-column tile (raw sums, every row written)
 hipError_t launch_panel_in(const int* in_rowptr, const int* in_off, const float* in_val, const float* B,
                            float* C, const int* panel_w0, int m, int n, int k, int R, int tile,
-                           hipStream_t s) {
+                           hipStream_t s, const int* dense_slot) {
   const size_t lds_bytes = sizeof(float) * (size_t)(PANEL_W * 64 + PANEL_WAVES * 64);
   static bool attr_done = false;
   if (!attr_done) {
@@ -449,10 +553,27 @@ hipError_t launch_panel_in(const int* in_rowptr, const int* in_off, const float*
   // four entries per LDS instruction when rows of C can take 16-byte stores
   if (quad_on && k % 4 == 0 && ((uintptr_t)C & 15) == 0)
     spmm_panel_in_quad_kernel<<<dim3(panels), dim3(PANEL_WAVES * 64), lds_bytes, s>>>(
-        in_rowptr, in_off, in_val, B, C, panel_w0, m, n, k, R, tile);
+        dense_slot, in_rowptr, in_off, in_val, B, C, panel_w0, m, n, k, R, tile);
   else
     spmm_panel_in_kernel<<<dim3(panels), dim3(PANEL_WAVES * 64), lds_bytes, s>>>(
-        in_rowptr, in_off, in_val, B, C, panel_w0, m, n, k, R, tile);
+        dense_slot, in_rowptr, in_off, in_val, B, C, panel_w0, m, n, k, R, tile);
+  return hipGetLastError();
+}
+
+// dense panels: C[rows of the panel, tile] = Adense * Bwin on the matrix cores (every row of those panels written)
+hipError_t launch_panel_dense(const float* adense, const int* dense_panel, int ndense, const float* B, float* C,
+                              const int* panel_w0, int m, int n, int k, int R, int tile, hipStream_t s) {
+  if (ndense <= 0) return hipSuccess;
+  const size_t lds_bytes = sizeof(float) * (size_t)(PANEL_W * 64);
+  static bool attr_done = false;
+  if (!attr_done) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_panel_dense_mfma_kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  spmm_panel_dense_mfma_kernel<<<dim3(ndense), dim3(MFMA_WAVES * 64), lds_bytes, s>>>(adense, dense_panel, B, C, panel_w0,
+                                                                                     m, n, k, R, tile);
   return hipGetLastError();
 }
 

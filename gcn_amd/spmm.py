@@ -130,6 +130,11 @@ class CsrAdjacency:
         return int(_lib.load().gcn_spmm_plan_panel_rows(self.plan))
 
     @property
+    def dense_panels(self):
+        """panels of the plan that run as dense tiles on the matrix cores (gcn_spmm_plan_dense_panels)"""
+        return int(_lib.load().gcn_spmm_plan_dense_panels(self.plan))
+
+    @property
     def panel_coverage(self):
         return float(_lib.load().gcn_spmm_plan_panel_coverage(self.plan))
 

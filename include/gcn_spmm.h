@@ -168,6 +168,12 @@ int gcn_spmm_plan_enable_panels(gcn_spmm_plan_t* plan, const int32_t* rowptr_dev
                                 const int32_t* col_dev, const float* val_dev, int32_t mode,
                                 void* stream);
 int32_t gcn_spmm_plan_panel_rows(const gcn_spmm_plan_t* plan);       /* rows per panel, 0 = off */
+/* Panels whose 128 x 512 window holds >= 25 % non-zeros are stored as dense fp32 tiles and contracted on the matrix
+ * cores (v_mfma_f32_32x32x2_f32: exact fp32) instead of entry by entry — the BASELINE north_star's "MFMA on the
+ * dense row-panel x feature-tile product where nnz-per-panel forms a dense contraction"; a window that holds a
+ * non-finite feature value falls back to entry-by-entry sums so that NaN/Inf never reach rows that do not reference
+ * them.  Returns how many panels of the plan take that path (0 when panels are off). */
+int32_t gcn_spmm_plan_dense_panels(const gcn_spmm_plan_t* plan);
 double gcn_spmm_plan_panel_coverage(const gcn_spmm_plan_t* plan);    /* fraction of nnz inside windows */
 
 /* Live kernel timing for bench.py: between _begin and _end every gcn_spmm_csr_f32*

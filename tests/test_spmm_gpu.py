@@ -756,3 +756,66 @@ def test_value_free_pass_with_slices_wider_than_the_15_bit_stream():
     B = np.random.default_rng(5).standard_normal((n, 128)).astype(np.float32)
     C = adj.matmul_raw(torch.from_numpy(B).to(_dev())).cpu().numpy()
     assert rel_err(C, oracle_spmm(rowptr, col, val, B)) <= TOL
+
+
+def _dense_band_csr(n, half_band, density, seed, sparse_from=None):
+    """rows hold `density` of the columns within +-half_band of the diagonal (rows >= sparse_from: 3 % instead),
+    plus a few far entries: the 128 x 512 windows of the panels are 25-60 % dense"""
+    rng = np.random.default_rng(seed)
+    rows, cols = [], []
+    for r in range(n):
+        lo, hi = max(0, r - half_band), min(n, r + half_band + 1)
+        dens = density if sparse_from is None or r < sparse_from else 0.03
+        c = np.flatnonzero(rng.random(hi - lo) < dens) + lo
+        far = rng.integers(0, n, 2)
+        c = np.unique(np.concatenate([c, far]))
+        rows.append(np.full(len(c), r)); cols.append(c)
+    rows, cols = np.concatenate(rows), np.concatenate(cols)
+    A = sp.csr_matrix(((rng.standard_normal(len(rows)) * 0.5).astype(np.float32), (rows, cols)), shape=(n, n))
+    A.sort_indices()
+    return A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.astype(np.float32)
+
+
+@pytest.mark.parametrize("k", [64, 128, 100, 36])
+def test_dense_panels_run_on_the_matrix_cores(k):
+    """panels whose 128 x 512 window is >= 25 % dense are stored as dense fp32 tiles and contracted with
+    v_mfma_f32_32x32x2_f32 (exact fp32: the 1e-5 contract holds); sparse panels of the same matrix keep the LDS
+    kernel, entries outside the windows the accumulate pass; last partial panel, window clipped at the matrix
+    edge, bias + ReLU"""
+    n = 2500                                              # 19.5 panels; the last window ends at the matrix edge
+    rowptr, col, val = _dense_band_csr(n, 200, 0.6, seed=k, sparse_from=1700)
+    d = _dev()
+    adj = _adj(rowptr, col, val, n, n, panels=1)
+    assert adj.panel_rows == 128 and 10 <= adj.dense_panels <= 14        # rows < 1700 dense, the rest sparse
+    rng = np.random.default_rng(k)
+    B = rng.standard_normal((n, k)).astype(np.float32)
+    bias = rng.standard_normal(k).astype(np.float32)
+    Bd = torch.from_numpy(B).to(d)
+    Cref = oracle_spmm(rowptr, col, val, B)
+    C = adj.matmul_raw(Bd)
+    assert rel_err(C.cpu().numpy(), Cref) <= TOL
+    assert torch.equal(C, adj.matmul_raw(Bd))                             # reproducible
+    C2 = adj.matmul_raw(Bd, bias=torch.from_numpy(bias).to(d), relu=True).cpu().numpy()
+    assert rel_err(C2, np.maximum(Cref + bias, 0)) <= TOL
+    auto = _adj(rowptr, col, val, n, n, panels="auto")                    # coverage >= 0.5: on by itself, same tiles
+    assert auto.dense_panels == adj.dense_panels
+    assert torch.equal(auto.matmul_raw(Bd), C)
+
+
+def test_dense_panels_keep_non_finite_features_out_of_rows_that_do_not_reference_them():
+    """a dense contraction would multiply the zeros of A with an Inf feature value (0 * Inf = NaN) and poison the
+    whole panel; a window that holds a non-finite value is summed entry by entry instead"""
+    n, k = 1536, 64
+    rowptr, col, val = _dense_band_csr(n, 200, 0.5, seed=3)
+    adj = _adj(rowptr, col, val, n, n, panels=1)
+    assert adj.dense_panels == 12
+    B = np.random.default_rng(3).standard_normal((n, k)).astype(np.float32)
+    B[300, 7] = np.inf; B[900, 50] = np.nan
+    C = adj.matmul_raw(torch.from_numpy(B).to(_dev())).cpu().numpy()
+    A = sp.csr_matrix((val, col, rowptr), shape=(n, n))
+    touched = np.asarray((A[:, [300, 900]] != 0).sum(1)).ravel() > 0
+    assert np.all(np.isfinite(C[~touched]))                                # nothing leaked
+    assert np.all(~np.isfinite(C[np.asarray((A[:, [300]] != 0).sum(1)).ravel() > 0, 7]))
+    Bf = B.copy(); Bf[300, 7] = 0.0; Bf[900, 50] = 0.0
+    Cref = oracle_spmm(rowptr, col, val, Bf)
+    assert rel_err(C[~touched], Cref[~touched]) <= TOL                     # and the clean rows are exact
