@@ -65,7 +65,10 @@ int env_int(const char* name, int dflt) { const char* e = std::getenv(name); ret
 bool valless_enabled() { static const bool v = env_on("GCN_AMD_VALLESS"); return v; }   // value-free sliced pass
 bool col16_enabled() { static const bool v = env_on("GCN_AMD_COL16"); return v; }       // its 16-bit column stream (quad kernel)
 bool group_enabled() { static const bool v = env_on("GCN_AMD_GROUP"); return v; }       // the group kernel (spmm_group.hip)
-bool group_sc1() { static const bool v = env_on("GCN_AMD_GROUP_SC1"); return v; }       // write-through partial-row stores
+int group_store() {                                                                     // partial-row stores: 0 plain, 1 sc1 (write-through), 2 nt
+  static const int v = [] { const int m = env_int("GCN_AMD_GROUP_STORE", 2); return (m >= 0 && m <= 2) ? m : 2; }();
+  return v;
+}
 int group_chunk() {                                                                     // entries per 16-lane group chunk
   static const int v = [] { const int t = env_int("GCN_AMD_GROUP_T", 512); return (t == 256 || t == 512 || t == 1024 || t == 2048) ? t : 512; }();
   return v;
@@ -122,20 +125,36 @@ int padded_ldb(long long n, int k) {
 //   n = 14.5 k (64-column table 3.7 MB): slicing buys nothing;  29 k (7.5 MB): [2] 0.352 vs 0.394 ms
 //   unsliced;  58 k: [4] 0.84 vs 1.18;  116 k: [4/8] 1.76-1.80 vs 3.13;  233 k: [8] 3.62 vs 7.3;
 //   466 k: [8] 9.20 vs 15.7 (16: 9.84);  932 k: [8] 24.4 vs 32.3;  1.86 M: [8] 56.5 vs 62.5.
-// So: as many slices as bring one slice of the table (n/S x 256 B) down to the 4 MiB of an XCD's L2,
-// but never more than the 8 XCDs — beyond 8 every XCD walks several slices and the extra partial rows
-// (S*m*k floats written and re-read) cost more than the higher hit rate returns (r02 group kernel, n = 233 k,
-// whole SpMM: S = 8 / 12 / 16 / 24: 3.21 / 3.23 / 3.31 / 3.65 ms, profiles/r02d_*).  Needs >= 16
-// non-zeros per virtual row; at mean degree 51 (products-shaped) slicing loses and stays off.
-int auto_slices(long long m, long long n, long long nnz) {
+// So, for matrices with a value stream (the four-per-gather kernel): as many slices as bring one slice of
+// the table (n/S x 256 B) down to the 4 MiB of an XCD's L2, but never more than the 8 XCDs — beyond 8 every
+// XCD walks several slices and the extra partial rows (S*m*k floats written and re-read) cost more than the
+// higher hit rate returns.
+// `value_free` (the values factor, the group kernel of spmm_group.hip runs): a partial row costs one
+// non-temporal 256-byte store and no cross-lane work, so the count follows the table alone — one slice per
+// 4 MiB of it (n = 233 k: 15), XCDs walking two slices each one after the other.  Measured
+// (profiles/r02z5_nt_stores_slices.log, whole SpMM k = 128): S = 8 / 14 / 16 / 18 / 20 / 24 / 32:
+// 3.19 / 3.08 / 3.09 / 3.13 / 3.19 / 3.36 / 3.68 ms — flat from 14 to 16, then the slab of partial rows
+// (S*m*k floats, written and re-read by the reduction) takes over.
+// Both need >= 16 non-zeros per virtual row; at mean degree 51 (products-shaped) slicing loses and stays off.
+int auto_slices(long long m, long long n, long long nnz, bool value_free) {
   if (m <= 0 || nnz <= 0) return 0;
   static const int forced = env_int("GCN_AMD_SLICES", -1);
   if (forced >= 0) return forced;                     // development knob: the slice count "auto" resolves to
   if (nnz / m < 128) return 0;                        // low degree: partial rows outweigh the hits
   const long long table = n * 256;                    // bytes of one 64-column tile of B
-  if (table <= (4LL << 20)) return 0;                 // fits every L2 as it is
+  const long long l2 = 4LL << 20;
+  if (table <= l2) return 0;                          // fits every L2 as it is
+  if (value_free) {
+    long long S = (table + l2 - 1) / l2;
+    const long long narrow = (n + 32766) / 32767;     // the group kernel's 15-bit entries: slices <= 32 767 columns
+    if (S < narrow) S = narrow;
+    if (S > 8) {                                      // (up to 8 the rule below gives the same or better)
+      if (S > nnz / m / 16) S = nnz / m / 16;         // keep >= 16 non-zeros per virtual row
+      if (S > 8 && S <= 1024 && S >= narrow && table / S <= 2 * l2) return (int)S;
+    }
+  }
   int S = 2;
-  while (S < 8 && table / S > (4LL << 20)) S *= 2;
+  while (S < 8 && table / S > l2) S *= 2;
   while (S > 1 && nnz / m / S < 16) S /= 2;           // keep >= 16 non-zeros per virtual row
   if (S < 2) return 0;
   // slices far larger than any cache (huge n): the partial rows cost traffic and buy no hits
@@ -336,7 +355,7 @@ int spmm_impl(gcn_spmm_plan* p, const int32_t* rowptr, const int32_t* col, const
     ga.stream = p->group.stream; ga.chunk_meta = p->group.chunk_meta;
     ga.Bp = a.B; ga.Cv = p->cv; ga.P = p->ws;
     ga.nchunks = p->group.nchunks; ga.T = p->group.T; ga.k = k; ga.ldb = a.ldb;
-    ga.write_through = gcn::group_sc1() ? 1 : 0;
+    ga.store_policy = gcn::group_store();
     if (ev0 && hipEventRecord(ev0, st) != hipSuccess) return GCN_ERR_HIP;
     if (gcn::launch_spmm_group(ga, st) != hipSuccess) return GCN_ERR_HIP;
     if (ev1 && hipEventRecord(ev1, st) != hipSuccess) return GCN_ERR_HIP;
@@ -527,12 +546,27 @@ int gcn_spmm_plan_enable_slicing(gcn_spmm_plan_t* p, const int32_t* rowptr, cons
   p->group = gcn::GroupStream{};
   p->cv.reset();
   const bool autom = slices == -1;
-  if (autom) slices = gcn::auto_slices(p->m, p->n, p->nnz);
-  if (slices <= 1 || p->nnz == 0 || p->m == 0) return GCN_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (p->nnz == 0 || p->m == 0 || slices == 0 || slices == 1) return GCN_OK;
   if (!rowptr || !col || !val) return GCN_ERR_INVALID_ARG;
+  // Normalised adjacencies (D^-1/2 (A+I) D^-1/2) have values u[r]*u[c]: when every stored entry matches
+  // that to 4 ulp the sliced main pass can run without its value stream, on a B whose rows were scaled by u,
+  // with the row factor applied in the slice reduction.  (Factors handed over by the caller stay.)  Looked
+  // for first: the automatic slice count depends on it.
+  if (p->m == p->n && gcn::valless_enabled() && !p->factors.ready() &&
+      (!autom || gcn::auto_slices(p->m, p->n, p->nnz, false) > 1)) {
+    gcn::DevBuf<float> u;
+    int ok = 0;
+    if (u.alloc((size_t)p->n) == hipSuccess &&
+        gcn::detect_rank1_values(rowptr, col, val, p->n, u, &ok, st) == hipSuccess && ok) {
+      p->factors.u_row = std::move(u);
+      p->factors.u_col = p->factors.u_row;
+    }
+  }
+  if (autom) slices = gcn::auto_slices(p->m, p->n, p->nnz, p->factors.ready() && gcn::group_enabled());
+  if (slices <= 1) return GCN_OK;
   if ((long long)slices * p->m + 1 >= (1LL << 31)) return GCN_ERR_INVALID_ARG;
   const long long vm = (long long)slices * p->m;
-  hipStream_t st = (hipStream_t)stream;
   gcn::Slicing sl;
   if (sl.vrowptr.alloc((size_t)(vm + 1)) != hipSuccess || sl.vcol.alloc((size_t)p->nnz) != hipSuccess ||
       sl.vval.alloc((size_t)p->nnz) != hipSuccess || sl.vchunk_row.alloc((size_t)p->nchunks) != hipSuccess)
@@ -546,19 +580,7 @@ int gcn_spmm_plan_enable_slicing(gcn_spmm_plan_t* p, const int32_t* rowptr, cons
     return GCN_ERR_HIP;
   sl.S = slices;
   p->slicing = std::move(sl);
-  // Normalised adjacencies (D^-1/2 (A+I) D^-1/2) have values u[r]*u[c]: when every stored entry matches
-  // that to 4 ulp the sliced main pass can run without its value stream, on a B whose rows were scaled by u,
-  // with the row factor applied in the slice reduction.  (Factors handed over by the caller stay.)
-  if (p->m == p->n && gcn::valless_enabled() && !p->factors.ready()) {
-    gcn::DevBuf<float> u;
-    int ok = 0;
-    if (u.alloc((size_t)p->n) == hipSuccess &&
-        gcn::detect_rank1_values(rowptr, col, val, p->n, u, &ok, st) == hipSuccess && ok) {
-      p->factors.u_row = std::move(u);
-      p->factors.u_col = p->factors.u_row;
-    }
-  }
-  build_valless_streams(p, st);                        // (only once the values are known to factor)
+  build_valless_streams(p, st);                        // (only when the values are known to factor)
   return GCN_OK;
 }
 
@@ -735,7 +757,7 @@ int gcn_spmm_plan_main_kernel(const gcn_spmm_plan_t* p, int32_t k, int32_t epilo
   }
   a.col16 = a.valless && p->col16.ready();
   if (a.valless && group_pass(p)) {
-    snprintf(buf, (size_t)buflen, "gcn::spmm_group_kernel<%d, %s>", p->group.T, gcn::group_sc1() ? "true" : "false");
+    snprintf(buf, (size_t)buflen, "gcn::spmm_group_kernel<%d, %d>", p->group.T, gcn::group_store());
     return GCN_OK;
   }
   gcn::describe_main_kernel(a, buf, (size_t)buflen);

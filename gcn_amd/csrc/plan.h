@@ -163,7 +163,7 @@ extern std::mutex g_plan_mu;                        // serialises workspace grow
 int cu_count_cached();
 int auto_chunk_nnz(long long nnz, int cu);
 int auto_tile_cols(long long n, int k);
-int auto_slices(long long m, long long n, long long nnz);
+int auto_slices(long long m, long long n, long long nnz, bool value_free = false);
 int padded_ldb(long long n, int k);
 bool pad_b_enabled();
 [[noreturn]] void die(const char* what, hipError_t e);

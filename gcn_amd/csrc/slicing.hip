@@ -141,6 +141,56 @@ slice_reduce_kernel(const float* __restrict__ Cv, float* __restrict__ C,
   }
 }
 
+// The same reduction for row widths that divide 256 floats (k = 4 .. 256, the widths of the 64-column tiles):
+// a wave covers 1 KiB of C at a time — 256 / k consecutive rows, every lane a float4 — so all 64 lanes load
+// whatever k is (the kernel above leaves half of them idle at k = 128), and the S partial rows are fetched
+// eight at a time with non-temporal loads (they are read exactly once) before they are added in slice order.
+typedef float slice_f32x4 __attribute__((ext_vector_type(4)));
+
+__global__ void __launch_bounds__(256)
+slice_reduce_wide_kernel(const float* __restrict__ Cv, float* __restrict__ C,
+                         const float* __restrict__ bias, int relu, int m, int S, int k, int accumulate,
+                         const float* __restrict__ rowscale, DropoutSpec drop) {
+  const int lane = threadIdx.x & 63;
+  const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long long nw = (long long)gridDim.x * 4;
+  const int rpw = 256 / k;                            // rows per wave and step
+  const int lr = lane * 4 / k, x = lane * 4 % k;
+  const size_t slab = (size_t)m * (size_t)k;          // floats between two slices' partial rows of one row
+  for (long long r0 = wave * rpw; r0 < m; r0 += nw * rpw) {
+    const long long r = r0 + lr;
+    if (r >= m) continue;
+    const float* p = Cv + (size_t)r * (size_t)k + x;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    int s = 0;
+    for (; s + 8 <= S; s += 8) {
+      slice_f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(reinterpret_cast<const slice_f32x4*>(p + (size_t)(s + u) * slab));
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+    }
+    for (; s < S; ++s) {
+      const slice_f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const slice_f32x4*>(p + (size_t)s * slab));
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    if (rowscale) { const float rs = rowscale[r]; acc.x *= rs; acc.y *= rs; acc.z *= rs; acc.w *= rs; }
+    float* o = C + (size_t)r * (size_t)k + x;
+    if (accumulate) {                                 // C already holds another part of the product
+      const float4 c = *reinterpret_cast<const float4*>(o);
+      acc.x += c.x; acc.y += c.y; acc.z += c.z; acc.w += c.w;
+    }
+    if (bias) {
+      const float4 b = *reinterpret_cast<const float4*>(bias + x);
+      acc.x += b.x; acc.y += b.y; acc.z += b.z; acc.w += b.w;
+    }
+    if (relu) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
+    if (drop.on())                                    // the dropout mask of the fused epilogue (philox.h)
+      acc = dropout_apply4(drop, (unsigned long long)r * (unsigned long long)k + (unsigned long long)x, acc);
+    *reinterpret_cast<float4*>(o) = acc;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
@@ -201,7 +251,11 @@ hipError_t launch_slice_reduce(const float* Cv, float* C, const float* bias, int
   int nb = (m + 3) / 4;
   if (nb > 8192) nb = 8192;
   const uintptr_t al = (uintptr_t)Cv | (uintptr_t)C | (uintptr_t)bias;
-  if (k % 4 == 0 && (al & 15) == 0) slice_reduce_kernel<4><<<nb, 256, 0, st>>>(Cv, C, bias, relu, m, S, k, accumulate, rowscale, drop);
+  if (k % 4 == 0 && 256 % k == 0 && (al & 15) == 0) {
+    const long long steps = ((long long)m * k + 255) / 256;      // wave steps of 1 KiB
+    const int nbw = (int)(steps / 4 + 1 < 16384 ? steps / 4 + 1 : 16384);
+    slice_reduce_wide_kernel<<<nbw, 256, 0, st>>>(Cv, C, bias, relu, m, S, k, accumulate, rowscale, drop);
+  } else if (k % 4 == 0 && (al & 15) == 0) slice_reduce_kernel<4><<<nb, 256, 0, st>>>(Cv, C, bias, relu, m, S, k, accumulate, rowscale, drop);
   else                              slice_reduce_kernel<1><<<nb, 256, 0, st>>>(Cv, C, bias, relu, m, S, k, accumulate, rowscale, drop);
   return hipGetLastError();
 }

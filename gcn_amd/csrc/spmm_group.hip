@@ -44,18 +44,25 @@ __device__ __forceinline__ int row_bcast(int v) {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// Partial-row store.  WT: write-through (sc1) — the line is dropped from the XCD's L2 instead of staying
-// there: the slab is read back only by the reduction that follows, and left in L2 its lines push out
-// feature rows the gathers are about to reuse (MI355X_MICROARCH.md, "stores of each flavour").  There is
-// no builtin for a 16-byte sc1 store; the trailing s_nop keeps the compiler's next instruction off the
-// data registers until the store has read them (cdna_hip_programming.md §5.7).
-template <bool WT>
+// Partial-row store, POLICY: 0 plain, 1 sc1 (write-through), 2 nt (streaming; the default).  The slab of
+// partial rows is read back only by the reduction that follows; left in L2 its lines push out feature rows
+// the gathers are about to reuse.  Measured (profiles/r02z2_row_end_store_ablation.log, r02z4_store_policy.log,
+// Reddit-shaped k = 128): with the store instruction alone removed the main passes run 2.69 ms at 8 slices and
+// 2.22 ms at 16 — the whole cost of a row end is its store; sc1 stores cost 2.86 / 2.76 ms (8 / 16 slices),
+// plain ones 2.86 / 2.71, nt ones 2.82 / 2.53.  tools/probes/store_probe.hip shows why: beside L2-served
+// gathers an sc1 store holds the vector-memory path ~30 cycles per instruction, a plain or nt one ~5, and
+// only sc1 and nt keep the written lines from displacing the table.  (There is no builtin for a 16-byte sc1
+// store; the trailing s_nop keeps the compiler's next instruction off the data registers until the store has
+// read them, cdna_hip_programming.md §5.7.)
+template <int POLICY>
 __device__ __forceinline__ void store_row_piece(float* dst, const float4& v) {
-  if constexpr (WT) {
-    const f32x4 t = {v.x, v.y, v.z, v.w};
+  const f32x4 t = {v.x, v.y, v.z, v.w};
+  if constexpr (POLICY == 1) {
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(dst), "v"(t) : "memory");
+  } else if constexpr (POLICY == 2) {
+    __builtin_nontemporal_store(t, reinterpret_cast<f32x4*>(dst));
   } else {
-    *reinterpret_cast<float4*>(dst) = v;
+    *reinterpret_cast<f32x4*>(dst) = t;
   }
 }
 
@@ -65,7 +72,7 @@ __device__ __forceinline__ void store_row_piece(float* dst, const float4& v) {
 // the chunk's slice in Bp}
 // Bp: scaled copy of B, slice s at rows [s*(w+1), (s+1)*(w+1)), row w of every slice all zero
 // nchunks % 32 == 0 (the stream is padded), so every XCD owns whole waves.
-template <int T, bool WT>
+template <int T, int POLICY>
 __global__ void __launch_bounds__(256)
 spmm_group_kernel(const unsigned short* __restrict__ stream, const int2* __restrict__ chunk_meta,
                   const float* __restrict__ Bp, float* __restrict__ Cv, float* __restrict__ P,
@@ -119,7 +126,7 @@ spmm_group_kernel(const unsigned short* __restrict__ stream, const int2* __restr
       GCN_G_ADD(UU)                                                                                 \
       if (ends & (0x0001000100010001ull << UU)) {                /* some group ends a row here */    \
         if (row_bcast<UU>((int)fl)) {                                                               \
-          if (fok) store_row_piece<WT>(ptr, acc);                            \
+          if (fok) store_row_piece<POLICY>(ptr, acc);                            \
           acc = make_float4(0.f, 0.f, 0.f, 0.f);                                                    \
           ptr = nptr; nptr += kk; first = false;                                                    \
         }                                                                                           \
@@ -133,7 +140,7 @@ spmm_group_kernel(const unsigned short* __restrict__ stream, const int2* __restr
   // the row piece that sticks out of the chunk's end (the last entry did not end its row)
   if (!row_bcast<15>((int)fl)) {
     float* dst = (head && first) ? ptr : P + (size_t)(2 * c + 1) * kk + fcol;
-    if (fok) store_row_piece<WT>(dst, acc);
+    if (fok) store_row_piece<POLICY>(dst, acc);
   }
 }
 
@@ -153,8 +160,9 @@ hipError_t launch_spmm_group(const GroupArgs& a, hipStream_t s) {
   for (int t = 0; t < tiles; ++t) {
 #define GCN_GROUP_ARGS a.stream, reinterpret_cast<const int2*>(a.chunk_meta), a.Bp, a.Cv, a.P, a.nchunks, a.k, t, ldb
 #define GCN_GROUP_LAUNCH(TT)                                                                              \
-      if (a.write_through) spmm_group_kernel<TT, true><<<dim3(nblocks), dim3(256), 0, s>>>(GCN_GROUP_ARGS);  \
-      else                 spmm_group_kernel<TT, false><<<dim3(nblocks), dim3(256), 0, s>>>(GCN_GROUP_ARGS); \
+      if (a.store_policy == 1)      spmm_group_kernel<TT, 1><<<dim3(nblocks), dim3(256), 0, s>>>(GCN_GROUP_ARGS);  \
+      else if (a.store_policy == 2) spmm_group_kernel<TT, 2><<<dim3(nblocks), dim3(256), 0, s>>>(GCN_GROUP_ARGS);  \
+      else                          spmm_group_kernel<TT, 0><<<dim3(nblocks), dim3(256), 0, s>>>(GCN_GROUP_ARGS);  \
       break;
     switch (a.T) {
       case 256:  GCN_GROUP_LAUNCH(256)
