@@ -63,6 +63,7 @@ int env_int(const char* name, int dflt) { const char* e = std::getenv(name); ret
 
 // development knobs, read once per process (DESIGN.md lists them)
 bool valless_enabled() { static const bool v = env_on("GCN_AMD_VALLESS"); return v; }   // value-free sliced pass
+int valless_min_per_col() { static const int v = env_int("GCN_AMD_VALLESS_MIN_PER_COL", 48); return v; }   // non-zeros per column from which the scaled copy pays
 bool col16_enabled() { static const bool v = env_on("GCN_AMD_COL16"); return v; }       // its 16-bit column stream (quad kernel)
 bool group_enabled() { static const bool v = env_on("GCN_AMD_GROUP"); return v; }       // the group kernel (spmm_group.hip)
 int group_store() {                                                                     // partial-row stores: 0 plain, 1 sc1 (write-through), 2 nt
@@ -209,15 +210,21 @@ bool sliced_for(const gcn_spmm_plan* p, int k) { return p->slicing.S > 0 && p->n
 // would the sliced launch of a k-wide SpMM run a value-free kernel (and is the scaled copy of B worth it)?
 bool valless_pays(const gcn_spmm_plan* p, int k, int ldb) {
   // (the scaled copy of B costs 2*n*k*4 bytes of traffic whatever the matrix; the value stream it saves is
-  //  4 bytes per non-zero plus instructions — measured break-even near 65 non-zeros per column of the
-  //  block: the rank-0 share of an 8-way partition of the Reddit-shaped graph (62 per column) does not gain)
-  if (!sliced_for(p, k) || !p->factors.ready() || p->panels.R != 0 || p->nnz / p->n < 96) return false;
+  //  4 bytes per non-zero plus instructions.  With the group kernel the rank-0 share of an 8-way partition of
+  //  the Reddit-shaped graph, 61 non-zeros per column of the block, still gains: 0.460 against 0.511 ms,
+  //  profiles/r02z7_rank_share_value_free.log; below 48 per column nothing has been measured, so it stays off)
+  if (!sliced_for(p, k) || !p->factors.ready() || p->panels.R != 0 || p->nnz / p->n < gcn::valless_min_per_col()) return false;
   if (p->group.ready() && gcn::spmm_group_eligible(k, ldb, nullptr, nullptr, nullptr)) return true;   // spmm_group.hip
   gcn::SpmmArgs t{};                                   // the launch as the sliced branch will issue it
   t.k = k; t.nnz = p->nnz; t.n = p->n; t.nchunks_grid = p->nchunks; t.T = p->T;
   t.m = p->slicing.S * p->m; t.ldb = ldb; t.tile_cols = p->tile_cols ? p->tile_cols : 64;
   t.gather_width = p->gather_width;
   return gcn::spmm_will_use_quad(t) && gcn::spmm_quad_lanes(k) == 16;
+}
+
+// will a sliced plan of this matrix run the group kernel (known before the slicing exists: it decides the slice count)
+bool value_free_plan(const gcn_spmm_plan* p) {
+  return p->factors.ready() && gcn::group_enabled() && p->panels.R == 0 && p->nnz / p->n >= gcn::valless_min_per_col();
 }
 
 // the value-free pass of this plan runs the group kernel (its scaled copy of B is then laid out slice by slice)
@@ -546,6 +553,7 @@ int gcn_spmm_plan_enable_slicing(gcn_spmm_plan_t* p, const int32_t* rowptr, cons
   p->group = gcn::GroupStream{};
   p->cv.reset();
   const bool autom = slices == -1;
+  p->slices_auto = autom;
   hipStream_t st = (hipStream_t)stream;
   if (p->nnz == 0 || p->m == 0 || slices == 0 || slices == 1) return GCN_OK;
   if (!rowptr || !col || !val) return GCN_ERR_INVALID_ARG;
@@ -563,7 +571,7 @@ int gcn_spmm_plan_enable_slicing(gcn_spmm_plan_t* p, const int32_t* rowptr, cons
       p->factors.u_col = p->factors.u_row;
     }
   }
-  if (autom) slices = gcn::auto_slices(p->m, p->n, p->nnz, p->factors.ready() && gcn::group_enabled());
+  if (autom) slices = gcn::auto_slices(p->m, p->n, p->nnz, value_free_plan(p));
   if (slices <= 1) return GCN_OK;
   if ((long long)slices * p->m + 1 >= (1LL << 31)) return GCN_ERR_INVALID_ARG;
   const long long vm = (long long)slices * p->m;
@@ -607,6 +615,9 @@ int gcn_spmm_plan_set_value_factors(gcn_spmm_plan_t* p, const int32_t* rowptr, c
     return GCN_ERR_HIP;
   f.u_col = f.u_col_own;
   p->factors = std::move(f);
+  // a slice count chosen automatically was chosen for a matrix WITH a value stream: choose again
+  if (p->slices_auto && gcn::auto_slices(p->m, p->n, p->nnz, value_free_plan(p)) != p->slicing.S)
+    return gcn_spmm_plan_enable_slicing(p, rowptr, col, val, -1, stream);
   build_valless_streams(p, st);
   return GCN_OK;
 }

@@ -150,6 +150,7 @@ struct gcn_spmm_plan {
   int gather_width = 0;                             // non-zeros per gather instruction of the 64-column kernel: 0 auto, 1, 4
   int blocks_per_cu = 32;                           // grid size: blocks of 4 waves per CU (oversubscribed on purpose)
   gcn::Slicing slicing;
+  bool slices_auto = false;                         // the slice count was chosen by auto_slices (enable_slicing(-1))
   gcn::Col16Stream col16;
   gcn::GroupStream group;
   gcn::Factors factors;
