@@ -366,8 +366,7 @@ int spmm_impl(gcn_spmm_plan* p, const int32_t* rowptr, const int32_t* col, const
     if (ev0 && hipEventRecord(ev0, st) != hipSuccess) return GCN_ERR_HIP;
     if (gcn::launch_spmm_group(ga, st) != hipSuccess) return GCN_ERR_HIP;
     if (ev1 && hipEventRecord(ev1, st) != hipSuccess) return GCN_ERR_HIP;
-    if (gcn::launch_spmm_fixup(p->group.vrowptr, p->ws, p->cv, p->group.chunk_row, p->group.nchunks, p->group.T, k, st) != hipSuccess)
-      return GCN_ERR_HIP;
+    if (gcn::launch_group_fixup(p->group.fix, p->group.nfix, p->ws, p->cv, k, st) != hipSuccess) return GCN_ERR_HIP;
     return gcn::launch_slice_reduce(p->cv, C, bias, relu, p->m, sl.S, k, st, 0, p->factors.u_row, epi.drop) == hipSuccess
                ? GCN_OK : GCN_ERR_HIP;
   }
@@ -398,13 +397,16 @@ void build_valless_streams(gcn_spmm_plan* p, hipStream_t st) {
   // 15-bit stream of the group kernel: slices at most 32 767 columns wide; best effort
   if (w <= 32767 && gcn::group_enabled() && p->group.vrowptr.alloc((size_t)(vm + 1)) == hipSuccess) {
     unsigned short* stream = nullptr;
-    int *chunk_row = nullptr, *chunk_meta = nullptr, nch = 0;
+    int *chunk_row = nullptr, *chunk_meta = nullptr, *fix = nullptr, nch = 0, nfix = 0;
     if (gcn::build_group_stream(sl.vrowptr, sl.vcol, p->m, p->n, sl.S, gcn::group_chunk(), p->group.vrowptr, &stream,
-                                &chunk_row, &chunk_meta, &nch, st) == hipSuccess && nch > 0) {
+                                &chunk_row, &chunk_meta, &nch, &fix, &nfix, st) == hipSuccess && nch > 0) {
+      p->group.fix.adopt(fix, 4 * (size_t)nfix); p->group.nfix = nfix;
       p->group.stream.adopt(stream, (size_t)nch * (size_t)gcn::group_chunk());
       p->group.chunk_row.adopt(chunk_row, (size_t)nch);
       p->group.chunk_meta.adopt(chunk_meta, 2 * (size_t)nch);
       p->group.nchunks = nch; p->group.T = gcn::group_chunk(); p->group.w = w;
+      p->group.chunk_row.reset();                      // (only the builder needed these two: the kernels read
+      p->group.vrowptr.reset();                        //  chunk_meta and the fix list)
       return;
     }
     p->group = gcn::GroupStream{};

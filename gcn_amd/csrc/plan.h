@@ -105,7 +105,8 @@ struct Col16Stream {
 struct GroupStream {
   DevBuf<unsigned short> stream;                    // [nchunks*T]
   DevBuf<int> chunk_row, vrowptr, chunk_meta;       // [nchunks], [S*m+1], int2 [nchunks]
-  int nchunks = 0, T = 0, w = 0;
+  DevBuf<int> fix;                                  // int4 [nfix]: rows cut by chunk ends {virtual row, c, c1, 0}
+  int nchunks = 0, T = 0, w = 0, nfix = 0;
   bool ready() const { return stream != nullptr; }
 };
 

@@ -377,15 +377,69 @@ __global__ void group_meta_kernel(const int* __restrict__ chunk_row, const int* 
   meta[c] = make_int2(2 * vr + (vrowptr_g[vr] < (long long)c * T ? 1 : 0), (vr / m) * (w + 1));
 }
 
+// fix[i] = {virtual row, c, c1, 0} for every row that begins in chunk c-1 and runs on into chunks c .. c1: the rows
+// whose pieces lie in the partial slab (group_fixup_kernel adds them up).  Order of the list: as the atomics fall —
+// every entry owns its row, so the results do not depend on it.
+__global__ void group_fix_list_kernel(const int2* __restrict__ meta, const int* __restrict__ vrowptr_g, int nchunks, int T,
+                                      int4* __restrict__ fix, int* __restrict__ nfix) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x + 1;
+  if (c >= nchunks) return;
+  const int2 mt = meta[c];
+  if (!(mt.x & 1)) return;
+  const int vr = mt.x >> 1;
+  if (vrowptr_g[vr] / T != c - 1) return;                        // began earlier still: the entry of that chunk covers it
+  fix[atomicAdd(nfix, 1)] = make_int4(vr, c, (vrowptr_g[vr + 1] - 1) / T, 0);
+}
+
+// Cv[row, :] = tail piece of chunk c-1 + head pieces of chunks c .. c1, in chunk order.  One thread per float4
+// of FOUR list entries (the loads of the four are in flight together: the pass is latency-bound otherwise).
+__global__ void __launch_bounds__(256)
+group_fixup_kernel(const int4* __restrict__ fix, int nfix, const float* __restrict__ P, float* __restrict__ Cv, int k) {
+  const int k4 = k >> 2;
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long e0 = t / k4 * 4;
+  const int x = (int)(t % k4) * 4;
+  if (e0 >= nfix) return;
+  int4 f[4];
+  float4 a[4], b[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) f[i] = fix[e0 + i < nfix ? e0 + i : e0];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    a[i] = *reinterpret_cast<const float4*>(P + (size_t)(2 * (f[i].y - 1) + 1) * (size_t)k + x);
+    b[i] = *reinterpret_cast<const float4*>(P + (size_t)(2 * f[i].y) * (size_t)k + x);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (e0 + i >= nfix) break;
+    float4 s = make_float4(a[i].x + b[i].x, a[i].y + b[i].y, a[i].z + b[i].z, a[i].w + b[i].w);
+    for (int cc = f[i].y + 1; cc <= f[i].z; ++cc) {              // rows longer than a chunk: whole chunks in between
+      const float4 v = *reinterpret_cast<const float4*>(P + (size_t)(2 * cc) * (size_t)k + x);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    *reinterpret_cast<float4*>(Cv + (size_t)f[i].x * (size_t)k + x) = s;
+  }
+}
+
+hipError_t launch_group_fixup(const int* fix, int nfix, const float* P, float* Cv, int k, hipStream_t s) {
+  if (nfix <= 0 || k <= 0) return hipSuccess;
+  if (k % 4 != 0) return hipErrorInvalidValue;
+  const long long threads = ((long long)nfix + 3) / 4 * (k / 4);
+  group_fixup_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, s>>>(reinterpret_cast<const int4*>(fix), nfix, P, Cv, k);
+  return hipGetLastError();
+}
+
 hipError_t build_group_stream(const int* vrowptr, const int* vcol, int m, int n, int S, int T, int* vrowptr_g,
                               unsigned short** stream_out, int** chunk_row_out, int** chunk_meta_out,
-                              int* nchunks_host, hipStream_t st) {
+                              int* nchunks_host, int** fix_out, int* nfix_host, hipStream_t st) {
   *stream_out = nullptr; *chunk_row_out = nullptr; *chunk_meta_out = nullptr; *nchunks_host = 0;
+  *fix_out = nullptr; *nfix_host = 0;
   const int w = (n + S - 1) / S;
   if (S < 1 || S > 256 || w > 32767 || m <= 0 || T < 16 || T % 16) return hipErrorInvalidValue;
   const long long vm = (long long)S * m;
-  int *len = nullptr, *pos = nullptr, *d_pad = nullptr, *chunk_row = nullptr;
+  int *len = nullptr, *pos = nullptr, *d_pad = nullptr, *chunk_row = nullptr, *nfix_dev = nullptr;
   int2* meta = nullptr;
+  int4* fix = nullptr;
   unsigned short* stream = nullptr;
   void* tmp = nullptr;
   size_t tmp_bytes = 0;
@@ -395,7 +449,13 @@ hipError_t build_group_stream(const int* vrowptr, const int* vcol, int m, int n,
     if (pos) (void)hipFree(pos);
     if (d_pad) (void)hipFree(d_pad);
     if (tmp) (void)hipFree(tmp);
-    if (all) { if (stream) (void)hipFree(stream); if (chunk_row) (void)hipFree(chunk_row); if (meta) (void)hipFree(meta); }
+    if (nfix_dev) (void)hipFree(nfix_dev);
+    if (all) {
+      if (stream) (void)hipFree(stream);
+      if (chunk_row) (void)hipFree(chunk_row);
+      if (meta) (void)hipFree(meta);
+      if (fix) (void)hipFree(fix);
+    }
   };
 #define GCN_GO(x) do { err = (x); if (err != hipSuccess) { cleanup(true); return err; } } while (0)
   GCN_GO(hipMalloc((void**)&len, sizeof(int) * (size_t)(vm + 1)));
@@ -436,10 +496,18 @@ hipError_t build_group_stream(const int* vrowptr, const int* vcol, int m, int n,
   GCN_GO(hipMalloc((void**)&meta, sizeof(int2) * (size_t)nchunks));
   group_meta_kernel<<<(nchunks + 255) / 256, 256, 0, st>>>(chunk_row, vrowptr_g, nchunks, T, m, w, meta);
   GCN_GO(hipGetLastError());
-  GCN_GO(hipStreamSynchronize(st));                              // (pad_before is a host buffer)
+  GCN_GO(hipMalloc((void**)&fix, sizeof(int4) * (size_t)nchunks));
+  GCN_GO(hipMalloc((void**)&nfix_dev, sizeof(int)));
+  GCN_GO(hipMemsetAsync(nfix_dev, 0, sizeof(int), st));
+  group_fix_list_kernel<<<(nchunks + 255) / 256, 256, 0, st>>>(meta, vrowptr_g, nchunks, T, fix, nfix_dev);
+  GCN_GO(hipGetLastError());
+  int nfix = 0;
+  GCN_GO(hipMemcpyAsync(&nfix, nfix_dev, sizeof(int), hipMemcpyDeviceToHost, st));
+  GCN_GO(hipStreamSynchronize(st));                              // (pad_before and nfix are host buffers)
 #undef GCN_GO
   cleanup(false);
   *stream_out = stream; *chunk_row_out = chunk_row; *chunk_meta_out = reinterpret_cast<int*>(meta); *nchunks_host = nchunks;
+  *fix_out = reinterpret_cast<int*>(fix); *nfix_host = nfix;
   return hipSuccess;
 }
 

@@ -44,8 +44,6 @@ struct SpmmArgs {
 hipError_t launch_plan_chunk_rows(const int* rowptr, int m, int T, int nchunks,
                                   int* chunk_row, hipStream_t s);
 hipError_t launch_spmm(const SpmmArgs& a, int cu_count, hipStream_t s);
-hipError_t launch_spmm_fixup(const int* rowptr, const float* P, float* C, const int* chunk_row, int nchunks, int T,
-                             int k, hipStream_t s);
 hipError_t launch_gather_rows(float* dst, const float* src, const int* idx, int nrows, int k,
                               hipStream_t s);
 // dst[r, 0:k] = src[r, 0:k], dst[r, k:ld] = 0 for r < rows (dst row stride ld >= k)
@@ -85,9 +83,12 @@ hipError_t launch_spmm_group(const GroupArgs& a, hipStream_t s);
 // entries that gather the slice's zero row.  Outputs: vrowptr_g [S*m+1] (caller-allocated; the fix-up pass needs
 // it), *stream_out, *chunk_row_out [nchunks] and *chunk_meta_out (int2 [nchunks], see GroupArgs) — allocated here,
 // the caller frees —, *nchunks_host.
+// *fix_out (int4 [*nfix_host], allocated here): the rows whose pieces lie in the partial slab, see launch_group_fixup.
 hipError_t build_group_stream(const int* vrowptr, const int* vcol, int m, int n, int S, int T, int* vrowptr_g,
                               unsigned short** stream_out, int** chunk_row_out, int** chunk_meta_out,
-                              int* nchunks_host, hipStream_t st);
+                              int* nchunks_host, int** fix_out, int* nfix_host, hipStream_t st);
+// Cv[row, :] = sum of the row's pieces in the partial slab P, in chunk order, for every row of the list (k % 4 == 0)
+hipError_t launch_group_fixup(const int* fix, int nfix, const float* P, float* Cv, int k, hipStream_t s);
 // dst[(c / w)*(w+1) + c % w, :] = rowscale[c] * src[c, :] (row stride ld >= k, padding columns zero), row w of
 // every slice zero: the layout GroupArgs::Bp describes
 hipError_t launch_scale_rows_sliced(float* dst, const float* src, const float* rowscale, int n, int k, int ld,

@@ -463,15 +463,6 @@ hipError_t launch_spmm(const SpmmArgs& a, int cu_count, hipStream_t s) {
   return e;
 }
 
-// the fix-up pass alone (callers that launch their own main kernel: spmm_group.hip)
-hipError_t launch_spmm_fixup(const int* rowptr, const float* P, float* C, const int* chunk_row, int nchunks, int T,
-                             int k, hipStream_t s) {
-  if (nchunks <= 1 || k <= 0) return hipSuccess;
-  const int nb = (nchunks - 1 + 3) / 4;
-  spmm_fixup_kernel<false><<<nb, 256, 0, s>>>(rowptr, P, C, chunk_row, nullptr, nullptr, 0, nchunks, T, k, 0);
-  return hipGetLastError();
-}
-
 // Name (as rocprofv3 prints it) of the main kernel launch_spmm picks for these arguments; mirrors the
 // selection above.  Used by gcn_spmm_plan_main_kernel so that a benchmark reports the kernel that runs.
 void describe_main_kernel(const SpmmArgs& a, char* buf, size_t len) {
