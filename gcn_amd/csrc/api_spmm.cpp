@@ -70,6 +70,7 @@ int group_store() {                                                             
   static const int v = [] { const int m = env_int("GCN_AMD_GROUP_STORE", 2); return (m >= 0 && m <= 2) ? m : 2; }();
   return v;
 }
+bool quad_stream_rows() { static const bool v = env_on("GCN_AMD_QUAD_NT"); return v; }   // sliced pass with values: nt partial-row stores
 int group_chunk() {                                                                     // entries per 16-lane group chunk
   static const int v = [] { const int t = env_int("GCN_AMD_GROUP_T", 512); return (t == 256 || t == 512 || t == 1024 || t == 2048) ? t : 512; }();
   return v;
@@ -372,6 +373,7 @@ int spmm_impl(gcn_spmm_plan* p, const int32_t* rowptr, const int32_t* col, const
   }
   a.rowptr = sl.vrowptr; a.col = sl.vcol; a.val = sl.vval; a.chunk_row = sl.vchunk_row;
   a.C = p->cv; a.m = sl.S * p->m; a.bias = nullptr; a.relu = 0;
+  a.stream_rows = gcn::quad_stream_rows() ? 1 : 0;
   const float* rowscale = nullptr;
   if (valless) {                                                          // B was scaled by u_col above
     a.valless = 1; a.val = nullptr; rowscale = p->factors.u_row;

@@ -30,6 +30,9 @@
 
 namespace gcn {
 
+typedef float f32x4_q __attribute__((ext_vector_type(4)));
+
+
 typedef const int __attribute__((address_space(4)))* const_int_ptr;
 
 __device__ __forceinline__ int qsgpr(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -82,9 +85,11 @@ spmm_quad_kernel(const int* __restrict__ g_rowptr, const int* __restrict__ g_col
                  float* __restrict__ g_C, float* __restrict__ g_P,
                  const int* __restrict__ g_chunk_row, const float* __restrict__ g_bias,
                  const int* __restrict__ nnz_dev,
-                 int relu, int nchunks, int T, int m, int nnz, int k, int col_tile, int accumulate, int ldb,
+                 int relu, int nchunks, int T, int m, int nnz, int k, int col_tile, int flags, int ldb,
                  QuadSlices sl, int n_rows_b) {
   static_assert(!COL16 || VALLESS, "16-bit columns are only built for the value-free pass");
+  const bool accumulate = flags & 1;                // C += ...
+  const bool stream_rows = flags & 2;               // finished rows leave with non-temporal stores (SpmmArgs::stream_rows)
   if (nnz_dev) {                                    // drop-in (flexspmm) mode, see spmm_kernels.hip
     nnz = *nnz_dev;
     nchunks = (int)(((long long)nnz + T - 1) / T);
@@ -151,7 +156,10 @@ spmm_quad_kernel(const int* __restrict__ g_rowptr, const int* __restrict__ g_col
           t.x += bias4.x; t.y += bias4.y; t.z += bias4.z; t.w += bias4.w;
           if (relu) { t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f); }
         }
-        if (writer) *dst = t;
+        if (writer) {
+          if (stream_rows) __builtin_nontemporal_store(f32x4_q{t.x, t.y, t.z, t.w}, reinterpret_cast<f32x4_q*>(dst));
+          else *dst = t;
+        }
       }
       acc = make_float4(0.f, 0.f, 0.f, 0.f);
       head = false;
@@ -260,7 +268,7 @@ static hipError_t launch_quad(const SpmmArgs& a, int nblocks, bool epi, hipStrea
   }
   for (int t = 0; t < tiles; ++t) {
 #define GCN_QUAD_ARGS a.rowptr, a.col, a.val, a.B, a.C, a.P, a.chunk_row, a.bias, a.nnz_dev, \
-                      a.relu, a.nchunks, a.T, a.m, a.nnz, a.k, t, a.accumulate, (a.ldb > 0 ? a.ldb : a.k), sl, a.n
+                      a.relu, a.nchunks, a.T, a.m, a.nnz, a.k, t, (a.accumulate ? 1 : 0) | (a.stream_rows ? 2 : 0), (a.ldb > 0 ? a.ldb : a.k), sl, a.n
     if constexpr (LPE == 16) {
       if (a.valless && !epi) {                       // (the value-free variants are only built for the sliced main pass)
         if (a.col16) spmm_quad_kernel<LPE, false, true, true><<<dim3(nblocks), dim3(256), 0, s>>>(GCN_QUAD_ARGS);
