@@ -697,6 +697,34 @@ def test_explicit_value_factors_on_a_row_block_with_renumbered_columns():
     assert rel_err(adj.matmul_raw(Bd).cpu().numpy(), Cref) <= TOL
 
 
+def test_automatic_slice_count_follows_the_value_factors():
+    """auto_slices: a matrix WITH a value stream gets at most one slice per XCD (8); once its values are known to
+    factor the group kernel runs and the count is one slice per 4 MiB of the 64-column table — also when the
+    factors arrive AFTER the automatic slicing (row blocks of the multi-GPU path: gcn_spmm_plan_set_value_factors
+    chooses again).  Sampled rows against the fp64 oracle on both plans."""
+    from util import sampled_rows_oracle_err
+    from gcn_amd import graphgen
+    d = _dev()
+    n, world = 170000, 8                                        # table 43.5 MB -> 11 slices value-free, 8 with values
+    rowptr, col, val, n, lo, hi, deg = graphgen.make_rmat_row_block(n, 60000000, world, 0, device=d, seed=9)
+    m = hi - lo
+    assert int(col.numel()) // m >= 128 and int(col.numel()) // n >= 48
+    adj = gcn_amd.CsrAdjacency(rowptr, col, val, (m, n), symmetric=False)
+    assert adj.num_slices == 8 and not adj.has_value_factors
+    B = torch.randn((n, 128), device=d, generator=torch.Generator(device=d).manual_seed(1))
+    rows = np.arange(0, m, max(1, m // 300), dtype=np.int64)
+    with_values = adj.matmul_raw(B)
+    assert sampled_rows_oracle_err(rowptr, col, val, B, with_values, rows)[0] <= TOL
+    u = graphgen.value_factor_from_degrees(deg)
+    adj.set_value_factors(u[lo:hi], u)
+    assert adj.has_value_factors and adj.num_slices == 11 and adj.main_kernel(128).startswith("gcn::spmm_group")
+    value_free = adj.matmul_raw(B)
+    assert sampled_rows_oracle_err(rowptr, col, val, B, value_free, rows)[0] <= TOL
+    adj.enable_slicing(4)                                       # an explicit count is kept
+    adj.set_value_factors(u[lo:hi], u)
+    assert adj.num_slices == 4
+
+
 def _hub_graph(n, e, hubs, seed):
     """normalised adjacency with a few vertices adjacent to (nearly) everything: virtual rows of n/S entries
     (they cross many chunks of the group kernel) next to rows with a handful of entries and empty slices"""
