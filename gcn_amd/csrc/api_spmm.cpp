@@ -70,6 +70,7 @@ int group_store() {                                                             
   static const int v = [] { const int m = env_int("GCN_AMD_GROUP_STORE", 2); return (m >= 0 && m <= 2) ? m : 2; }();
   return v;
 }
+bool group_weighted_enabled() { static const bool v = env_on("GCN_AMD_GROUP_WEIGHTED"); return v; }   // group kernel for values that do not factor
 bool quad_stream_rows() { static const bool v = env_on("GCN_AMD_QUAD_NT"); return v; }   // sliced pass with values: nt partial-row stores
 int group_chunk() {                                                                     // entries per 16-lane group chunk
   static const int v = [] { const int t = env_int("GCN_AMD_GROUP_T", 512); return (t == 256 || t == 512 || t == 1024 || t == 2048) ? t : 512; }();
@@ -215,6 +216,7 @@ bool valless_pays(const gcn_spmm_plan* p, int k, int ldb) {
   //  the Reddit-shaped graph, 61 non-zeros per column of the block, still gains: 0.460 against 0.511 ms,
   //  profiles/r02z7_rank_share_value_free.log; below 48 per column nothing has been measured, so it stays off)
   if (!sliced_for(p, k) || !p->factors.ready() || p->panels.R != 0 || p->nnz / p->n < gcn::valless_min_per_col()) return false;
+  if (p->group.vals) return false;                     // (the plan was built for the weighted pass: value-free did not pay)
   if (p->group.ready() && gcn::spmm_group_eligible(k, ldb, nullptr, nullptr, nullptr)) return true;   // spmm_group.hip
   gcn::SpmmArgs t{};                                   // the launch as the sliced branch will issue it
   t.k = k; t.nnz = p->nnz; t.n = p->n; t.nchunks_grid = p->nchunks; t.T = p->T;
@@ -223,13 +225,26 @@ bool valless_pays(const gcn_spmm_plan* p, int k, int ldb) {
   return gcn::spmm_will_use_quad(t) && gcn::spmm_quad_lanes(k) == 16;
 }
 
-// will a sliced plan of this matrix run the group kernel (known before the slicing exists: it decides the slice count)
+// will a sliced plan of this matrix run the group kernel value-free (known before the slicing exists)
 bool value_free_plan(const gcn_spmm_plan* p) {
   return p->factors.ready() && gcn::group_enabled() && p->panels.R == 0 && p->nnz / p->n >= gcn::valless_min_per_col();
+}
+// ... or the group kernel at all (value-free or weighted): it decides the automatic slice count
+bool group_plan(const gcn_spmm_plan* p) {
+  return value_free_plan(p) || (gcn::group_enabled() && gcn::group_weighted_enabled() && p->panels.R == 0);
+}
+// the sliced launch of a k-wide SpMM runs the WEIGHTED group kernel (values beside the stream)
+bool weighted_pass(const gcn_spmm_plan* p, int k, int ldb) {
+  return sliced_for(p, k) && p->panels.R == 0 && p->group.ready() && p->group.vals &&
+         gcn::spmm_group_eligible(k, ldb, nullptr, nullptr, nullptr);
 }
 
 // the value-free pass of this plan runs the group kernel (its scaled copy of B is then laid out slice by slice)
 bool group_pass(const gcn_spmm_plan* p) { return p->group.ready(); }
+// a launch decided as (valless, weighted) runs one of the group kernels: B is gathered from the slice-by-slice copy
+bool group_launch(const gcn_spmm_plan* p, bool valless, bool weighted) {
+  return weighted || (valless && p->group.ready() && !p->group.vals);
+}
 
 // Widths that are not a multiple of 4 take a detour over k' = k rounded up to 4 (gcn_spmm_csr_f32_epilogue); it
 // exists to reach the 16-byte-per-lane kernels, so it follows their rule: the four-per-gather kernel only pays
@@ -240,7 +255,7 @@ bool odd_width_detour(const gcn_spmm_plan* p, int k) {
   if ((long long)sizeof(float) * p->n * ldb > (768LL << 20)) return false;
   if (p->gather_width == 4) return true;
   const bool sliced = sliced_for(p, k);
-  if (sliced && p->group.ready() && p->factors.ready() && p->nnz / p->n >= 96) return true;
+  if (sliced && p->group.ready() && (p->group.vals || value_free_plan(p))) return true;
   const long long rows = sliced ? (long long)p->slicing.S * p->m : (long long)p->m;
   return rows > 0 && p->nnz / rows >= 48;
 }
@@ -248,13 +263,13 @@ bool odd_width_detour(const gcn_spmm_plan* p, int k) {
 // Copy of B the sliced main pass gathers from: rows `ldb` floats apart (>= k, padding columns zero), scaled by
 // u_col when `scaled`; one all-zero row more than B has (16-bit stream) or, for the group kernel, slice s at
 // rows [s*(w+1), (s+1)*(w+1)) with row w of every slice zero.
-int relay_B(gcn_spmm_plan* p, const float* B, int k, int ldb, bool scaled, hipStream_t st) {
-  if (scaled && group_pass(p)) {
+int relay_B(gcn_spmm_plan* p, const float* B, int k, int ldb, bool scaled, bool group_layout, hipStream_t st) {
+  if (group_layout) {                                  // (weighted pass: the same layout, rows not scaled)
     const size_t rows = (size_t)p->slicing.S * (size_t)(p->group.w + 1);
     const int rc = grow(p->bpad, rows * (size_t)ldb);
     if (rc != GCN_OK) return rc;
-    return gcn::launch_scale_rows_sliced(p->bpad, B, p->factors.u_col, p->n, k, ldb, p->slicing.S, p->group.w, st) == hipSuccess
-               ? GCN_OK : GCN_ERR_HIP;
+    return gcn::launch_scale_rows_sliced(p->bpad, B, scaled ? p->factors.u_col : nullptr, p->n, k, ldb, p->slicing.S, p->group.w,
+                                         st) == hipSuccess ? GCN_OK : GCN_ERR_HIP;
   }
   const int rc = grow(p->bpad, ((size_t)p->n + 1) * (size_t)ldb);
   if (rc != GCN_OK) return rc;
@@ -294,15 +309,17 @@ int spmm_impl(gcn_spmm_plan* p, const int32_t* rowptr, const int32_t* col, const
   // with its rows padded to the next multiple of 32 floats (one streaming copy, ~45 us for 233 k x 100)
   // and gathered from there; C keeps the caller's layout.  The same copy carries the row scaling of the
   // value-free pass (values u[r]*u[c], sliced matrix): B' = diag(u) B.
-  bool valless = false;
+  bool valless = false, weighted = false;
   if (b_ld > 0) {
     a.ldb = b_ld;                                      // already re-laid (and maybe scaled) by the caller (odd-width path)
     valless = b_scaled;
+    weighted = !valless && weighted_pass(p, k, b_ld);
   } else if (p->nnz > 0) {
     const int ldb = gcn::padded_ldb(p->n, k);
     valless = valless_pays(p, k, ldb);
-    if (ldb != k || valless) {
-      const int rc = relay_B(p, B, k, ldb, valless, st);
+    weighted = !valless && weighted_pass(p, k, ldb);
+    if (ldb != k || valless || weighted) {
+      const int rc = relay_B(p, B, k, ldb, valless, group_launch(p, valless, weighted), st);
       if (rc != GCN_OK) return rc;
       a.B = p->bpad;
       a.ldb = ldb;
@@ -357,10 +374,11 @@ int spmm_impl(gcn_spmm_plan* p, const int32_t* rowptr, const int32_t* col, const
   const gcn::Slicing& sl = p->slicing;
   if (grow(p->cv, (size_t)sl.S * (size_t)p->m * (size_t)k) != GCN_OK) return GCN_ERR_ALLOC;
   *dropped = epi.drop.on();
-  if (valless && group_pass(p)) {
+  if (group_launch(p, valless, weighted)) {
     // four independent 16-lane row engines per wave on the 15-bit slice-major stream (spmm_group.hip)
     gcn::GroupArgs ga;
     ga.stream = p->group.stream; ga.chunk_meta = p->group.chunk_meta;
+    ga.vals = weighted ? p->group.vals.get() : nullptr;
     ga.Bp = a.B; ga.Cv = p->cv; ga.P = p->ws;
     ga.nchunks = p->group.nchunks; ga.T = p->group.T; ga.k = k; ga.ldb = a.ldb;
     ga.store_policy = gcn::group_store();
@@ -368,8 +386,8 @@ int spmm_impl(gcn_spmm_plan* p, const int32_t* rowptr, const int32_t* col, const
     if (gcn::launch_spmm_group(ga, st) != hipSuccess) return GCN_ERR_HIP;
     if (ev1 && hipEventRecord(ev1, st) != hipSuccess) return GCN_ERR_HIP;
     if (gcn::launch_group_fixup(p->group.fix, p->group.nfix, p->ws, p->cv, k, st) != hipSuccess) return GCN_ERR_HIP;
-    return gcn::launch_slice_reduce(p->cv, C, bias, relu, p->m, sl.S, k, st, 0, p->factors.u_row, epi.drop) == hipSuccess
-               ? GCN_OK : GCN_ERR_HIP;
+    return gcn::launch_slice_reduce(p->cv, C, bias, relu, p->m, sl.S, k, st, 0, weighted ? nullptr : p->factors.u_row.get(),
+                                    epi.drop) == hipSuccess ? GCN_OK : GCN_ERR_HIP;
   }
   a.rowptr = sl.vrowptr; a.col = sl.vcol; a.val = sl.vval; a.chunk_row = sl.vchunk_row;
   a.C = p->cv; a.m = sl.S * p->m; a.bias = nullptr; a.relu = 0;
@@ -390,20 +408,25 @@ int spmm_impl(gcn_spmm_plan* p, const int32_t* rowptr, const int32_t* col, const
              ? GCN_OK : GCN_ERR_HIP;
 }
 
-// the value-free streams of a sliced plan whose values factor (built once both facts are known)
-void build_valless_streams(gcn_spmm_plan* p, hipStream_t st) {
+// the streams of a sliced plan beside its virtual CSR: the group kernel's (value-free when the values factor and
+// the scaled copy pays, else with the values beside it), or the 16-bit columns of the value-free four-per-gather pass
+void build_sliced_streams(gcn_spmm_plan* p, hipStream_t st) {
   gcn::Slicing& sl = p->slicing;
-  if (sl.S <= 1 || !p->factors.ready() || p->group.ready() || p->col16.ready()) return;
+  if (sl.S <= 1 || p->group.ready() || p->col16.ready() || (!group_plan(p) && !p->factors.ready())) return;
   const long long vm = (long long)sl.S * p->m;
   const int w = (p->n + sl.S - 1) / sl.S;
+  const bool value_free = value_free_plan(p);
   // 15-bit stream of the group kernel: slices at most 32 767 columns wide; best effort
-  if (w <= 32767 && gcn::group_enabled() && p->group.vrowptr.alloc((size_t)(vm + 1)) == hipSuccess) {
+  if (w <= 32767 && group_plan(p) && p->group.vrowptr.alloc((size_t)(vm + 1)) == hipSuccess) {
     unsigned short* stream = nullptr;
+    float* vals = nullptr;
     int *chunk_row = nullptr, *chunk_meta = nullptr, *fix = nullptr, nch = 0, nfix = 0;
     if (gcn::build_group_stream(sl.vrowptr, sl.vcol, p->m, p->n, sl.S, gcn::group_chunk(), p->group.vrowptr, &stream,
-                                &chunk_row, &chunk_meta, &nch, &fix, &nfix, st) == hipSuccess && nch > 0) {
+                                &chunk_row, &chunk_meta, &nch, &fix, &nfix, st, value_free ? nullptr : sl.vval.get(),
+                                value_free ? nullptr : &vals) == hipSuccess && nch > 0) {
       p->group.fix.adopt(fix, 4 * (size_t)nfix); p->group.nfix = nfix;
       p->group.stream.adopt(stream, (size_t)nch * (size_t)gcn::group_chunk());
+      if (vals) p->group.vals.adopt(vals, (size_t)nch * (size_t)gcn::group_chunk());
       p->group.chunk_row.adopt(chunk_row, (size_t)nch);
       p->group.chunk_meta.adopt(chunk_meta, 2 * (size_t)nch);
       p->group.nchunks = nch; p->group.T = gcn::group_chunk(); p->group.w = w;
@@ -413,6 +436,7 @@ void build_valless_streams(gcn_spmm_plan* p, hipStream_t st) {
     }
     p->group = gcn::GroupStream{};
   }
+  if (!p->factors.ready()) return;
   // 16-bit column stream of the four-per-gather kernel (2 instead of 4 index bytes per non-zero): slices at
   // most 65 535 columns wide, at most 8 of them; best effort — without it the 32-bit stream is used
   if (sl.S <= 8 && w <= 65535 && gcn::col16_enabled() && p->col16.vrowptr16.alloc((size_t)(vm + 1)) == hipSuccess) {
@@ -511,7 +535,8 @@ int gcn_spmm_csr_f32_epilogue(gcn_spmm_plan_t* p, const int32_t* rowptr, const i
     const int kp = (k + 3) / 4 * 4, ldb = (kp + 31) / 32 * 32;
     if (grow(p->cpad, (size_t)p->m * (size_t)kp) != GCN_OK) return GCN_ERR_ALLOC;
     const bool scaled = valless_pays(p, kp, ldb);      // the copy can carry the u_col scaling
-    if ((rc = relay_B(p, B, k, ldb, scaled, st)) != GCN_OK) return rc;
+    const bool weighted = !scaled && weighted_pass(p, kp, ldb);
+    if ((rc = relay_B(p, B, k, ldb, scaled, group_launch(p, scaled, weighted), st)) != GCN_OK) return rc;
     if ((rc = spmm_impl(p, rowptr, col, val, p->bpad, ldb, scaled, p->cpad, Epilogue{}, kp, st, &dropped)) != GCN_OK) return rc;
     if (gcn::launch_unpad_rows(C, p->cpad, bias, epi.relu, p->m, k, kp, st) != hipSuccess) return GCN_ERR_HIP;
     dropped = false;
@@ -575,7 +600,7 @@ int gcn_spmm_plan_enable_slicing(gcn_spmm_plan_t* p, const int32_t* rowptr, cons
       p->factors.u_col = p->factors.u_row;
     }
   }
-  if (autom) slices = gcn::auto_slices(p->m, p->n, p->nnz, value_free_plan(p));
+  if (autom) slices = gcn::auto_slices(p->m, p->n, p->nnz, group_plan(p));
   if (slices <= 1) return GCN_OK;
   if ((long long)slices * p->m + 1 >= (1LL << 31)) return GCN_ERR_INVALID_ARG;
   const long long vm = (long long)slices * p->m;
@@ -592,7 +617,7 @@ int gcn_spmm_plan_enable_slicing(gcn_spmm_plan_t* p, const int32_t* rowptr, cons
     return GCN_ERR_HIP;
   sl.S = slices;
   p->slicing = std::move(sl);
-  build_valless_streams(p, st);                        // (only when the values are known to factor)
+  build_sliced_streams(p, st);
   return GCN_OK;
 }
 
@@ -620,9 +645,9 @@ int gcn_spmm_plan_set_value_factors(gcn_spmm_plan_t* p, const int32_t* rowptr, c
   f.u_col = f.u_col_own;
   p->factors = std::move(f);
   // a slice count chosen automatically was chosen for a matrix WITH a value stream: choose again
-  if (p->slices_auto && gcn::auto_slices(p->m, p->n, p->nnz, value_free_plan(p)) != p->slicing.S)
+  if (p->slices_auto && gcn::auto_slices(p->m, p->n, p->nnz, group_plan(p)) != p->slicing.S)
     return gcn_spmm_plan_enable_slicing(p, rowptr, col, val, -1, stream);
-  build_valless_streams(p, st);
+  build_sliced_streams(p, st);
   return GCN_OK;
 }
 
@@ -773,6 +798,10 @@ int gcn_spmm_plan_main_kernel(const gcn_spmm_plan_t* p, int32_t k, int32_t epilo
   a.col16 = a.valless && p->col16.ready();
   if (a.valless && group_pass(p)) {
     snprintf(buf, (size_t)buflen, "gcn::spmm_group_kernel<%d, %d>", p->group.T, gcn::group_store());
+    return GCN_OK;
+  }
+  if (!a.valless && weighted_pass(p, a.k, a.ldb > 0 ? a.ldb : a.k)) {
+    snprintf(buf, (size_t)buflen, "gcn::spmm_group_weighted_kernel<%d, %d>", p->group.T, gcn::group_store());
     return GCN_OK;
   }
   gcn::describe_main_kernel(a, buf, (size_t)buflen);

@@ -101,9 +101,10 @@ struct Col16Stream {
   bool ready() const { return vcol16 != nullptr; }
 };
 
-// value-free pass, slices <= 32 767 columns: 15-bit slice-major stream of the group kernel (spmm_group.hip)
+// slices <= 32 767 columns: 15-bit slice-major stream of the group kernel (spmm_group.hip), value-free or weighted
 struct GroupStream {
   DevBuf<unsigned short> stream;                    // [nchunks*T]
+  DevBuf<float> vals;                               // [nchunks*T] values in stream order (weighted pass), empty: value-free
   DevBuf<int> chunk_row, vrowptr, chunk_meta;       // [nchunks], [S*m+1], int2 [nchunks]
   DevBuf<int> fix;                                  // int4 [nfix]: rows cut by chunk ends {virtual row, c, c1, 0}
   int nchunks = 0, T = 0, w = 0, nfix = 0;

@@ -350,11 +350,20 @@ __global__ void group_rowptr_kernel(const int* __restrict__ pos, int m, int S, c
   vrowptr_g[vr] = pos[vr] + pad_before[(int)(vr / m)];       // vr == S*m -> pad_before[S] = all the padding
 }
 
+// Where logical stream position p lives in memory: every run of 64 entries (four 16-entry blocks of one group) is
+// stored transposed, lane-major — [lane f][block j] — so that lane f of the group fetches ITS entries of four
+// consecutive blocks with one 8-byte load (spmm_group.hip: one stream load per 64 gathers instead of four).
+__device__ __forceinline__ long long group_phys(long long p) {
+  const int r = (int)(p & 63);
+  return (p & ~63LL) + (r & 15) * 4 + (r >> 4);
+}
+
 // one wave per virtual row: entries = column offset inside the slice; the LAST stream position the row owns
 // (which for the last row of a slice is the end of the slice's padding) carries the row-end bit
 __global__ void __launch_bounds__(256)
 group_scatter_kernel(const int* __restrict__ vrowptr, const int* __restrict__ vcol, const int* __restrict__ vrowptr_g,
-                     int m, int S, int w, unsigned short* __restrict__ stream) {
+                     int m, int S, int w, unsigned short* __restrict__ stream,
+                     const float* __restrict__ vval, float* __restrict__ vals) {
   const int lane = threadIdx.x & 63;
   const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const long long nw = (long long)gridDim.x * 4;
@@ -362,9 +371,11 @@ group_scatter_kernel(const int* __restrict__ vrowptr, const int* __restrict__ vc
     const int base = (int)(vr / m) * w;
     const int src = vrowptr[vr], len = vrowptr[vr + 1] - src;
     const int dst = vrowptr_g[vr], last = vrowptr_g[vr + 1] - 1;
-    for (int i = lane; i < len; i += 64)
-      stream[dst + i] = (unsigned short)((vcol[src + i] - base) | (dst + i == last ? 0x8000 : 0));
-    if (lane == 0 && last >= dst + len) stream[last] = (unsigned short)(w | 0x8000);   // padding entry ends the row
+    for (int i = lane; i < len; i += 64) {
+      stream[group_phys(dst + i)] = (unsigned short)((vcol[src + i] - base) | (dst + i == last ? 0x8000 : 0));
+      if (vals) vals[group_phys(dst + i)] = vval[src + i];
+    }
+    if (lane == 0 && last >= dst + len) stream[group_phys(last)] = (unsigned short)(w | 0x8000);   // padding entry ends the row
   }
 }
 
@@ -431,7 +442,9 @@ hipError_t launch_group_fixup(const int* fix, int nfix, const float* P, float* C
 
 hipError_t build_group_stream(const int* vrowptr, const int* vcol, int m, int n, int S, int T, int* vrowptr_g,
                               unsigned short** stream_out, int** chunk_row_out, int** chunk_meta_out,
-                              int* nchunks_host, int** fix_out, int* nfix_host, hipStream_t st) {
+                              int* nchunks_host, int** fix_out, int* nfix_host, hipStream_t st,
+                              const float* vval, float** vals_out) {
+  if (vals_out) *vals_out = nullptr;
   *stream_out = nullptr; *chunk_row_out = nullptr; *chunk_meta_out = nullptr; *nchunks_host = 0;
   *fix_out = nullptr; *nfix_host = 0;
   const int w = (n + S - 1) / S;
@@ -440,6 +453,7 @@ hipError_t build_group_stream(const int* vrowptr, const int* vcol, int m, int n,
   int *len = nullptr, *pos = nullptr, *d_pad = nullptr, *chunk_row = nullptr, *nfix_dev = nullptr;
   int2* meta = nullptr;
   int4* fix = nullptr;
+  float* vals = nullptr;
   unsigned short* stream = nullptr;
   void* tmp = nullptr;
   size_t tmp_bytes = 0;
@@ -455,6 +469,7 @@ hipError_t build_group_stream(const int* vrowptr, const int* vcol, int m, int n,
       if (chunk_row) (void)hipFree(chunk_row);
       if (meta) (void)hipFree(meta);
       if (fix) (void)hipFree(fix);
+      if (vals) (void)hipFree(vals);
     }
   };
 #define GCN_GO(x) do { err = (x); if (err != hipSuccess) { cleanup(true); return err; } } while (0)
@@ -489,7 +504,11 @@ hipError_t build_group_stream(const int* vrowptr, const int* vcol, int m, int n,
   {
     int nb = (int)((vm + 3) / 4);
     if (nb > 16384) nb = 16384;
-    group_scatter_kernel<<<nb, 256, 0, st>>>(vrowptr, vcol, vrowptr_g, m, S, w, stream);
+    if (vval && vals_out) {
+      GCN_GO(hipMalloc((void**)&vals, sizeof(float) * (size_t)total));
+      GCN_GO(hipMemsetAsync(vals, 0, sizeof(float) * (size_t)total, st));     // padding entries weigh nothing
+    }
+    group_scatter_kernel<<<nb, 256, 0, st>>>(vrowptr, vcol, vrowptr_g, m, S, w, stream, vval, vals);
   }
   GCN_GO(hipGetLastError());
   GCN_GO(launch_plan_chunk_rows(vrowptr_g, (int)vm, T, nchunks, chunk_row, st));
@@ -508,6 +527,7 @@ hipError_t build_group_stream(const int* vrowptr, const int* vcol, int m, int n,
   cleanup(false);
   *stream_out = stream; *chunk_row_out = chunk_row; *chunk_meta_out = reinterpret_cast<int*>(meta); *nchunks_host = nchunks;
   *fix_out = reinterpret_cast<int*>(fix); *nfix_host = nfix;
+  if (vals_out) *vals_out = vals;
   return hipSuccess;
 }
 
@@ -525,7 +545,7 @@ scale_rows_sliced_kernel(float* __restrict__ dst, const float* __restrict__ src,
     const long long c = (long long)s * w + j;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (j < w && c < n && x < k) {
-      const float u = rowscale[c];
+      const float u = rowscale ? rowscale[c] : 1.f;
       const float* p = src + c * k + x;
       if ((k & 3) == 0) { const float4 t = *reinterpret_cast<const float4*>(p); v = make_float4(u * t.x, u * t.y, u * t.z, u * t.w); }
       else { v.x = u * p[0]; if (x + 1 < k) v.y = u * p[1]; if (x + 2 < k) v.z = u * p[2]; if (x + 3 < k) v.w = u * p[3]; }

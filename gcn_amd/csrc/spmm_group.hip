@@ -23,12 +23,12 @@
 // of an XCD take consecutive chunks in dispatch order, so an XCD walks its part of the stream front to
 // back and slices meet its L2 one after the other (with more chunks per wave, as before, the second
 // chunk of an early wave ran beside the first chunk of a late one: two slices in one L2).
-// Row pieces that cross chunk ends go to the partial slab P and are added by spmm_fixup_kernel in chunk
+// Row pieces that cross chunk ends go to the partial slab P and are added by group_fixup_kernel (slicing.hip) in chunk
 // order, as everywhere else: results are bitwise reproducible.
 //
-// Value-free only (every stored entry counts 1): the caller gathers from a copy of B whose rows were
-// scaled by u_col and scales finished rows by u_row (api.cpp); matrices whose values do not factor keep
-// the four-per-gather kernel.
+// Value-free (spmm_group_kernel: every stored entry counts 1; the caller gathers from a copy of B whose rows
+// were scaled by u_col and scales finished rows by u_row, api_spmm.cpp) or, for values that do not factor,
+// with one fp32 value per entry beside the stream (spmm_group_weighted_kernel).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -67,16 +67,17 @@ __device__ __forceinline__ void store_row_piece(float* dst, const float4& v) {
 }
 
 // stream  [nchunks*T] u16: bits 0..14 column offset inside the slice (== slice width: the all-zero row),
-//                          bit 15 = last entry of its virtual row
+//                          bit 15 = last entry of its virtual row; every run of 64 entries stored lane-major (group_phys)
 // chunk_meta [nchunks]: {2 * (virtual row holding entry c*T) + (that row began in an earlier chunk), first row of
 // the chunk's slice in Bp}
 // Bp: scaled copy of B, slice s at rows [s*(w+1), (s+1)*(w+1)), row w of every slice all zero
 // nchunks % 32 == 0 (the stream is padded), so every XCD owns whole waves.
-template <int T, int POLICY>
-__global__ void __launch_bounds__(256)
-spmm_group_kernel(const unsigned short* __restrict__ stream, const int2* __restrict__ chunk_meta,
-                  const float* __restrict__ Bp, float* __restrict__ Cv, float* __restrict__ P,
-                  int nchunks, int k, int col_tile, int ldb) {
+// vals (VALS only) [nchunks*T]: the matrix values in stream order, 0 at padding entries
+template <int T, int POLICY, bool VALS>
+__device__ __forceinline__ void
+group_walk(const unsigned short* __restrict__ stream, const float* __restrict__ vals, const int2* __restrict__ chunk_meta,
+           const float* __restrict__ Bp, float* __restrict__ Cv, float* __restrict__ P,
+           int nchunks, int k, int col_tile, int ldb) {
   const int lane = threadIdx.x & 63;
   const int wib  = threadIdx.x >> 6;
   const int g    = lane >> 4;
@@ -101,14 +102,27 @@ spmm_group_kernel(const unsigned short* __restrict__ stream, const int2* __restr
   float* nptr = Cv + (size_t)(vrow + 1) * kk + fcol;
   bool first = true;                                            // no row of this chunk has ended yet
 
-  const unsigned short* __restrict__ sp = stream + (size_t)c * T + f;
+  // the stream is stored in runs of 64 entries, lane-major (slicing.hip, group_phys): lane f reads its entries of
+  // four consecutive blocks with one 8-byte load (16 bytes for the values)
+  static_assert(T % 64 == 0, "a chunk is whole runs of four blocks");
+  const uint2* __restrict__ sp = reinterpret_cast<const uint2*>(stream + (size_t)c * T) + f;
+  const f32x4* __restrict__ vp = VALS ? reinterpret_cast<const f32x4*>(vals + (size_t)c * T) + f : nullptr;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  unsigned e_nx = sp[0];
+  uint2 eq = sp[0], eq_nx = eq;
+  f32x4 vq = {0.f, 0.f, 0.f, 0.f}, vq_nx = vq;
+  if constexpr (VALS) { vq = __builtin_nontemporal_load(vp); vq_nx = vq; }   // (read once: keep it from displacing the table)
   unsigned fl = 0;
 #pragma unroll 1
   for (int blk = 0; blk < T / 16; ++blk) {
-    const unsigned e = e_nx;
-    if (blk + 1 < T / 16) e_nx = sp[(blk + 1) * 16];
+    const int j = blk & 3;
+    if (j == 0 && blk + 4 < T / 16) {                           // the next run, a whole run ahead of its use
+      eq_nx = sp[(blk / 4 + 1) * 16];
+      if constexpr (VALS) vq_nx = __builtin_nontemporal_load(vp + (blk / 4 + 1) * 16);
+    }
+    const unsigned e = ((j & 2 ? eq.y : eq.x) >> (16 * (j & 1))) & 0xFFFFu;
+    int vbits = 0;                                              // this lane's entry's value; step u takes lane u's
+    if constexpr (VALS) vbits = __builtin_bit_cast(int, j == 0 ? vq.x : j == 1 ? vq.y : j == 2 ? vq.z : vq.w);
+    if (j == 3) { eq = eq_nx; vq = vq_nx; }
     const int rowoff = (int)(__umul24((e & 0x7FFFu) + (unsigned)base, row_bytes));
     fl = e >> 15;
     float4 b[16];
@@ -119,7 +133,12 @@ spmm_group_kernel(const unsigned short* __restrict__ stream, const int2* __restr
 #undef GCN_G_GATHER
     const unsigned long long ends = __ballot(fl != 0);          // bit g*16+u: entry u of group g ends a row
     if (ends == 0ull) {
-#define GCN_G_ADD(UU) acc.x += b[UU].x; acc.y += b[UU].y; acc.z += b[UU].z; acc.w += b[UU].w;
+#define GCN_G_ADD(UU)                                                                               \
+      if constexpr (VALS) {                                                                         \
+        const float vu = __builtin_bit_cast(float, row_bcast<UU>(vbits));                           \
+        acc.x = fmaf(vu, b[UU].x, acc.x); acc.y = fmaf(vu, b[UU].y, acc.y);                         \
+        acc.z = fmaf(vu, b[UU].z, acc.z); acc.w = fmaf(vu, b[UU].w, acc.w);                         \
+      } else { acc.x += b[UU].x; acc.y += b[UU].y; acc.z += b[UU].z; acc.w += b[UU].w; }
       GCN_G_ALL(GCN_G_ADD)
     } else {
 #define GCN_G_STEP(UU)                                                                              \
@@ -144,6 +163,25 @@ spmm_group_kernel(const unsigned short* __restrict__ stream, const int2* __restr
   }
 }
 
+template <int T, int POLICY>
+__global__ void __launch_bounds__(256)
+spmm_group_kernel(const unsigned short* __restrict__ stream, const int2* __restrict__ chunk_meta,
+                  const float* __restrict__ Bp, float* __restrict__ Cv, float* __restrict__ P,
+                  int nchunks, int k, int col_tile, int ldb) {
+  group_walk<T, POLICY, false>(stream, nullptr, chunk_meta, Bp, Cv, P, nchunks, k, col_tile, ldb);
+}
+
+// the same walk for matrices whose values do not factor: one fp32 value per entry beside the 16-bit stream,
+// handed from the lane that loaded it to its group by the same DPP broadcast as the address (one more vector
+// instruction and four FMAs instead of two packed adds per step); Bp is then a plain (unscaled) sliced copy of B
+template <int T, int POLICY>
+__global__ void __launch_bounds__(256)
+spmm_group_weighted_kernel(const unsigned short* __restrict__ stream, const float* __restrict__ vals,
+                           const int2* __restrict__ chunk_meta, const float* __restrict__ Bp, float* __restrict__ Cv,
+                           float* __restrict__ P, int nchunks, int k, int col_tile, int ldb) {
+  group_walk<T, POLICY, true>(stream, vals, chunk_meta, Bp, Cv, P, nchunks, k, col_tile, ldb);
+}
+
 bool spmm_group_eligible(int k, int ldb, const void* B, const void* C, const void* P) {
   const uintptr_t al = (uintptr_t)B | (uintptr_t)C | (uintptr_t)P;
   if (ldb <= 0) ldb = k;
@@ -158,11 +196,14 @@ hipError_t launch_spmm_group(const GroupArgs& a, hipStream_t s) {
   const int tiles = (a.k + 63) / 64;
   const int ldb = a.ldb > 0 ? a.ldb : a.k;
   for (int t = 0; t < tiles; ++t) {
-#define GCN_GROUP_ARGS a.stream, reinterpret_cast<const int2*>(a.chunk_meta), a.Bp, a.Cv, a.P, a.nchunks, a.k, t, ldb
-#define GCN_GROUP_LAUNCH(TT)                                                                              \
-      if (a.store_policy == 1)      spmm_group_kernel<TT, 1><<<dim3(nblocks), dim3(256), 0, s>>>(GCN_GROUP_ARGS);  \
-      else if (a.store_policy == 2) spmm_group_kernel<TT, 2><<<dim3(nblocks), dim3(256), 0, s>>>(GCN_GROUP_ARGS);  \
-      else                          spmm_group_kernel<TT, 0><<<dim3(nblocks), dim3(256), 0, s>>>(GCN_GROUP_ARGS);  \
+#define GCN_GROUP_REST reinterpret_cast<const int2*>(a.chunk_meta), a.Bp, a.Cv, a.P, a.nchunks, a.k, t, ldb
+#define GCN_GROUP_PICK(KERNEL, TT, ...)                                                                  \
+      if (a.store_policy == 1)      KERNEL<TT, 1><<<dim3(nblocks), dim3(256), 0, s>>>(__VA_ARGS__);     \
+      else if (a.store_policy == 2) KERNEL<TT, 2><<<dim3(nblocks), dim3(256), 0, s>>>(__VA_ARGS__);     \
+      else                          KERNEL<TT, 0><<<dim3(nblocks), dim3(256), 0, s>>>(__VA_ARGS__);
+#define GCN_GROUP_LAUNCH(TT)                                                                             \
+      if (a.vals) { GCN_GROUP_PICK(spmm_group_weighted_kernel, TT, a.stream, a.vals, GCN_GROUP_REST) }   \
+      else        { GCN_GROUP_PICK(spmm_group_kernel, TT, a.stream, GCN_GROUP_REST) }                    \
       break;
     switch (a.T) {
       case 256:  GCN_GROUP_LAUNCH(256)
@@ -172,7 +213,8 @@ hipError_t launch_spmm_group(const GroupArgs& a, hipStream_t s) {
       default: return hipErrorInvalidValue;
     }
 #undef GCN_GROUP_LAUNCH
-#undef GCN_GROUP_ARGS
+#undef GCN_GROUP_PICK
+#undef GCN_GROUP_REST
   }
   return hipGetLastError();
 }

@@ -70,6 +70,7 @@ hipError_t launch_spmm_quad(const SpmmArgs& a, int nblocks, bool epi, hipStream_
 // spmm_group.hip — value-free sliced main pass, four independent 16-lane row engines per wave
 struct GroupArgs {
   const unsigned short* stream;  // [nchunks*T]: bits 0..14 column offset inside the slice, bit 15 = row end
+  const float* vals = nullptr;   // [nchunks*T] matrix values in stream order (0 at padding entries); nullptr: every entry counts 1
   const int* chunk_meta;         // int2 [nchunks]: {2 * (virtual row holding entry c*T) + (it began in an earlier chunk),
                                  //                  first row of the chunk's slice in Bp}
   const float* Bp;               // scaled copy of B: slice s at rows [s*(w+1), (s+1)*(w+1)), row w all zero
@@ -86,12 +87,14 @@ hipError_t launch_spmm_group(const GroupArgs& a, hipStream_t s);
 // it), *stream_out, *chunk_row_out [nchunks] and *chunk_meta_out (int2 [nchunks], see GroupArgs) — allocated here,
 // the caller frees —, *nchunks_host.
 // *fix_out (int4 [*nfix_host], allocated here): the rows whose pieces lie in the partial slab, see launch_group_fixup.
+// vval + vals_out (optional): the slice-major values are laid out beside the stream (*vals_out [nchunks*T], 0 at padding).
 hipError_t build_group_stream(const int* vrowptr, const int* vcol, int m, int n, int S, int T, int* vrowptr_g,
                               unsigned short** stream_out, int** chunk_row_out, int** chunk_meta_out,
-                              int* nchunks_host, int** fix_out, int* nfix_host, hipStream_t st);
+                              int* nchunks_host, int** fix_out, int* nfix_host, hipStream_t st,
+                              const float* vval = nullptr, float** vals_out = nullptr);
 // Cv[row, :] = sum of the row's pieces in the partial slab P, in chunk order, for every row of the list (k % 4 == 0)
 hipError_t launch_group_fixup(const int* fix, int nfix, const float* P, float* Cv, int k, hipStream_t s);
-// dst[(c / w)*(w+1) + c % w, :] = rowscale[c] * src[c, :] (row stride ld >= k, padding columns zero), row w of
+// dst[(c / w)*(w+1) + c % w, :] = rowscale[c] * src[c, :] (rowscale nullptr: 1; row stride ld >= k, padding columns zero), row w of
 // every slice zero: the layout GroupArgs::Bp describes
 hipError_t launch_scale_rows_sliced(float* dst, const float* src, const float* rowscale, int n, int k, int ld,
                                     int S, int w, hipStream_t s);

@@ -654,16 +654,19 @@ def test_value_free_sliced_pass_for_normalised_adjacencies():
         adj = _adj(rowptr, col, val, n, n, slices=S)
         assert adj.num_slices == S and adj.main_kernel(128).startswith("gcn::spmm_group")
         assert rel_err(adj.matmul_raw(torch.from_numpy(B).to(_dev())).cpu().numpy(), Cref) <= TOL
-    # one entry off by 1e-4 relative: no longer rank-1 -> the ordinary kernel, and the right answer
+    # one entry off by 1e-4 relative: no longer rank-1 -> the same walk WITH its values, and the right answer
     val2 = val.copy(); val2[len(val2) // 2] *= 1.0001
     adj2 = _adj(rowptr, col, val2, n, n)
-    assert adj2.num_slices >= 2 and adj2.main_kernel(128) == "gcn::spmm_quad_kernel<16, false, false, false>"
+    assert adj2.num_slices >= 2 and adj2.main_kernel(128).startswith("gcn::spmm_group_weighted_kernel<")
     B = rng.standard_normal((n, 128)).astype(np.float32)
     assert rel_err(adj2.matmul_raw(torch.from_numpy(B).to(_dev())).cpu().numpy(), oracle_spmm(rowptr, col, val2, B)) <= TOL
     # arbitrary weights
     val3 = (rng.random(len(val)) + 0.1).astype(np.float32)
     adj3 = _adj(rowptr, col, val3, n, n)
-    assert adj3.main_kernel(128) == "gcn::spmm_quad_kernel<16, false, false, false>"
+    assert adj3.main_kernel(128).startswith("gcn::spmm_group_weighted_kernel<")
+    for k in (64, 100, 41):                              # 100, 41: on the row-padded / odd-width copies
+        Bk = rng.standard_normal((n, k)).astype(np.float32)
+        assert rel_err(adj3.matmul_raw(torch.from_numpy(Bk).to(_dev())).cpu().numpy(), oracle_spmm(rowptr, col, val3, Bk)) <= TOL
     assert rel_err(adj3.matmul_raw(torch.from_numpy(B).to(_dev())).cpu().numpy(), oracle_spmm(rowptr, col, val3, B)) <= TOL
 
 
@@ -680,9 +683,9 @@ def test_explicit_value_factors_on_a_row_block_with_renumbered_columns():
     Ablk = A[lo:hi][:, np.argsort(perm)].tocsr(); Ablk.sort_indices()   # column j of the block = old column argsort(perm)[j]
     u_col = u[np.argsort(perm)]
     rp, ci, va = Ablk.indptr.astype(np.int32), Ablk.indices.astype(np.int32), Ablk.data.astype(np.float32)
-    adj = _adj(rp, ci, va, hi - lo, n, slices=2)                # 75 non-zeros per virtual row: the quad kernel
+    adj = _adj(rp, ci, va, hi - lo, n, slices=2)
     assert not adj.has_value_factors                            # rectangular: nothing to detect
-    assert adj.main_kernel(128) == "gcn::spmm_quad_kernel<16, false, false, false>"
+    assert adj.main_kernel(128).startswith("gcn::spmm_group_weighted_kernel<")
     B = np.random.default_rng(3).standard_normal((n, 128)).astype(np.float32)
     Bd = torch.from_numpy(B).to(_dev())
     plain = adj.matmul_raw(Bd).cpu().numpy()
@@ -698,26 +701,27 @@ def test_explicit_value_factors_on_a_row_block_with_renumbered_columns():
 
 
 def test_automatic_slice_count_follows_the_value_factors():
-    """auto_slices: a matrix WITH a value stream gets at most one slice per XCD (8); once its values are known to
-    factor the group kernel runs and the count is one slice per 4 MiB of the 64-column table — also when the
-    factors arrive AFTER the automatic slicing (row blocks of the multi-GPU path: gcn_spmm_plan_set_value_factors
-    chooses again).  Sampled rows against the fp64 oracle on both plans."""
+    """auto_slices on the group-kernel path: one slice per 4 MiB of the 64-column table, with the values beside the
+    stream until they are known to factor, value-free afterwards — also when the factors arrive AFTER the automatic
+    slicing (row blocks of the multi-GPU path: gcn_spmm_plan_set_value_factors rebuilds the streams).  Sampled rows
+    against the fp64 oracle on both plans; an explicit slice count is kept."""
     from util import sampled_rows_oracle_err
     from gcn_amd import graphgen
     d = _dev()
-    n, world = 170000, 8                                        # table 43.5 MB -> 11 slices value-free, 8 with values
+    n, world = 170000, 8                                        # table 43.5 MB -> 11 slices
     rowptr, col, val, n, lo, hi, deg = graphgen.make_rmat_row_block(n, 60000000, world, 0, device=d, seed=9)
     m = hi - lo
     assert int(col.numel()) // m >= 128 and int(col.numel()) // n >= 48
     adj = gcn_amd.CsrAdjacency(rowptr, col, val, (m, n), symmetric=False)
-    assert adj.num_slices == 8 and not adj.has_value_factors
+    assert adj.num_slices == 11 and not adj.has_value_factors
+    assert adj.main_kernel(128).startswith("gcn::spmm_group_weighted_kernel<")
     B = torch.randn((n, 128), device=d, generator=torch.Generator(device=d).manual_seed(1))
     rows = np.arange(0, m, max(1, m // 300), dtype=np.int64)
     with_values = adj.matmul_raw(B)
     assert sampled_rows_oracle_err(rowptr, col, val, B, with_values, rows)[0] <= TOL
     u = graphgen.value_factor_from_degrees(deg)
     adj.set_value_factors(u[lo:hi], u)
-    assert adj.has_value_factors and adj.num_slices == 11 and adj.main_kernel(128).startswith("gcn::spmm_group")
+    assert adj.has_value_factors and adj.num_slices == 11 and adj.main_kernel(128).startswith("gcn::spmm_group_kernel<")
     value_free = adj.matmul_raw(B)
     assert sampled_rows_oracle_err(rowptr, col, val, B, value_free, rows)[0] <= TOL
     adj.enable_slicing(4)                                       # an explicit count is kept
@@ -784,6 +788,12 @@ def test_value_free_pass_with_slices_wider_than_the_15_bit_stream():
     B = np.random.default_rng(5).standard_normal((n, 128)).astype(np.float32)
     C = adj.matmul_raw(torch.from_numpy(B).to(_dev())).cpu().numpy()
     assert rel_err(C, oracle_spmm(rowptr, col, val, B)) <= TOL
+    # ... and values that do not factor keep the four-per-gather kernel with its 32-bit columns and value stream
+    val2 = val.copy(); val2[7] *= 1.01
+    adj2 = _adj(rowptr, col, val2, n, n, slices=2)
+    adj2.set_gather_width(4)
+    assert not adj2.has_value_factors and adj2.main_kernel(128) == "gcn::spmm_quad_kernel<16, false, false, false>"
+    assert rel_err(adj2.matmul_raw(torch.from_numpy(B).to(_dev())).cpu().numpy(), oracle_spmm(rowptr, col, val2, B)) <= TOL
 
 
 def _dense_band_csr(n, half_band, density, seed, sparse_from=None):
