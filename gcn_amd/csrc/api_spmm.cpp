@@ -70,6 +70,7 @@ int group_store() {                                                             
   static const int v = [] { const int m = env_int("GCN_AMD_GROUP_STORE", 2); return (m >= 0 && m <= 2) ? m : 2; }();
   return v;
 }
+bool group_ring() { static const bool v = env_on("GCN_AMD_GROUP_RING"); return v; }   // finished rows through the LDS ring (value-free pass)
 bool group_weighted_enabled() { static const bool v = env_on("GCN_AMD_GROUP_WEIGHTED"); return v; }   // group kernel for values that do not factor
 bool quad_stream_rows() { static const bool v = env_on("GCN_AMD_QUAD_NT"); return v; }   // sliced pass with values: nt partial-row stores
 int group_chunk() {                                                                     // entries per 16-lane group chunk
@@ -382,6 +383,7 @@ int spmm_impl(gcn_spmm_plan* p, const int32_t* rowptr, const int32_t* col, const
     ga.Bp = a.B; ga.Cv = p->cv; ga.P = p->ws;
     ga.nchunks = p->group.nchunks; ga.T = p->group.T; ga.k = k; ga.ldb = a.ldb;
     ga.store_policy = gcn::group_store();
+    ga.ring = gcn::group_ring() ? 1 : 0;
     if (ev0 && hipEventRecord(ev0, st) != hipSuccess) return GCN_ERR_HIP;
     if (gcn::launch_spmm_group(ga, st) != hipSuccess) return GCN_ERR_HIP;
     if (ev1 && hipEventRecord(ev1, st) != hipSuccess) return GCN_ERR_HIP;
@@ -797,7 +799,7 @@ int gcn_spmm_plan_main_kernel(const gcn_spmm_plan_t* p, int32_t k, int32_t epilo
   }
   a.col16 = a.valless && p->col16.ready();
   if (a.valless && group_pass(p)) {
-    snprintf(buf, (size_t)buflen, "gcn::spmm_group_kernel<%d, %d>", p->group.T, gcn::group_store());
+    snprintf(buf, (size_t)buflen, "gcn::spmm_group%s_kernel<%d, %d>", gcn::group_ring() ? "_ring" : "", p->group.T, gcn::group_store());
     return GCN_OK;
   }
   if (!a.valless && weighted_pass(p, a.k, a.ldb > 0 ? a.ldb : a.k)) {

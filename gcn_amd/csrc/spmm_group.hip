@@ -73,7 +73,7 @@ __device__ __forceinline__ void store_row_piece(float* dst, const float4& v) {
 // Bp: scaled copy of B, slice s at rows [s*(w+1), (s+1)*(w+1)), row w of every slice all zero
 // nchunks % 32 == 0 (the stream is padded), so every XCD owns whole waves.
 // vals (VALS only) [nchunks*T]: the matrix values in stream order, 0 at padding entries
-template <int T, int POLICY, bool VALS>
+template <int T, int POLICY, bool VALS, bool RING>
 __device__ __forceinline__ void
 group_walk(const unsigned short* __restrict__ stream, const float* __restrict__ vals, const int2* __restrict__ chunk_meta,
            const float* __restrict__ Bp, float* __restrict__ Cv, float* __restrict__ P,
@@ -101,6 +101,22 @@ group_walk(const unsigned short* __restrict__ stream, const float* __restrict__ 
   float* ptr  = head ? P + (size_t)(2 * c) * kk + fcol : Cv + (size_t)vrow * kk + fcol;
   float* nptr = Cv + (size_t)(vrow + 1) * kk + fcol;
   bool first = true;                                            // no row of this chunk has ended yet
+  // RING: finished rows wait in LDS, four slots per group, and leave four at a time — consecutive rows of ONE group,
+  // written by the whole wave with one 64-lane store instead of four 16-lane ones (a store occupies the addressers
+  // like a gather whatever its width)
+  __shared__ f32x4 ring[RING ? 4 : 1][4][4][16];
+  int ring_n = 0;                                               // rows of this lane's group waiting in the ring
+  float* ring_base = nullptr;                                   // ... the first of them goes here (the next ones kk further each)
+#define GCN_G_DRAIN(G2, ROWS)                                                                       \
+  {                                                                                                 \
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(uintptr_t)ring_base, 16 * G2);    \
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)((uintptr_t)ring_base >> 32), 16 * G2); \
+    float* b0 = reinterpret_cast<float*>(((uintptr_t)hi << 32) | lo);                              \
+    const f32x4 rv = ring[wib][G2][lane >> 4][f];                                                   \
+    if (fok && (lane >> 4) < (ROWS))                                                                \
+      store_row_piece<POLICY>(b0 + (size_t)(lane >> 4) * kk + f * 4, make_float4(rv.x, rv.y, rv.z, rv.w)); \
+    if (g == G2) ring_n = 0;                                                                        \
+  }
 
   // the stream is stored in runs of 64 entries, lane-major (slicing.hip, group_phys): lane f reads its entries of
   // four consecutive blocks with one 8-byte load (16 bytes for the values)
@@ -150,7 +166,11 @@ group_walk(const unsigned short* __restrict__ stream, const float* __restrict__ 
       GCN_G_ADD(UU)                                                                                 \
       if (ends & (0x0001000100010001ull << UU)) {                /* some group ends a row here */    \
         if (row_bcast<UU>((int)fl)) {                                                               \
-          if (fok) store_row_piece<POLICY>(ptr, acc);                            \
+          if (RING && !(first && head) && ring_n < 4) {                                             \
+            if (fok) ring[wib][g][ring_n][f] = f32x4{acc.x, acc.y, acc.z, acc.w};                   \
+            if (ring_n == 0) ring_base = ptr;                                                       \
+            ++ring_n;                                                                               \
+          } else if (fok) store_row_piece<POLICY>(ptr, acc);                                        \
           acc = make_float4(0.f, 0.f, 0.f, 0.f);                                                    \
           ptr = nptr; nptr += kk; first = false;                                                    \
         }                                                                                           \
@@ -158,9 +178,26 @@ group_walk(const unsigned short* __restrict__ stream, const float* __restrict__ 
       GCN_G_ALL(GCN_G_STEP)
 #undef GCN_G_STEP
 #undef GCN_G_ADD
+      if constexpr (RING) {
+        const unsigned long long full = __ballot(ring_n == 4);
+        if (full) {
+          if (full & 0x0000000000000001ull) GCN_G_DRAIN(0, 4)
+          if (full & 0x0000000000010000ull) GCN_G_DRAIN(1, 4)
+          if (full & 0x0000000100000000ull) GCN_G_DRAIN(2, 4)
+          if (full & 0x0001000000000000ull) GCN_G_DRAIN(3, 4)
+        }
+      }
     }
 #undef GCN_G_ALL
   }
+  if constexpr (RING) {                                         // what is left in the rings
+    const unsigned long long some = __ballot(ring_n > 0);
+    if (some & 0x0000000000000001ull) GCN_G_DRAIN(0, __builtin_amdgcn_readlane(ring_n, 0))
+    if (some & 0x0000000000010000ull) GCN_G_DRAIN(1, __builtin_amdgcn_readlane(ring_n, 16))
+    if (some & 0x0000000100000000ull) GCN_G_DRAIN(2, __builtin_amdgcn_readlane(ring_n, 32))
+    if (some & 0x0001000000000000ull) GCN_G_DRAIN(3, __builtin_amdgcn_readlane(ring_n, 48))
+  }
+#undef GCN_G_DRAIN
   // the row piece that sticks out of the chunk's end (the last entry did not end its row)
   if (!row_bcast<15>((int)fl)) {
     float* dst = (head && first) ? ptr : P + (size_t)(2 * c + 1) * kk + fcol;
@@ -173,7 +210,15 @@ __global__ void __launch_bounds__(256)
 spmm_group_kernel(const unsigned short* __restrict__ stream, const int2* __restrict__ chunk_meta,
                   const float* __restrict__ Bp, float* __restrict__ Cv, float* __restrict__ P,
                   int nchunks, int k, int col_tile, int ldb, int stream_nt) {
-  group_walk<T, POLICY, false>(stream, nullptr, chunk_meta, Bp, Cv, P, nchunks, k, col_tile, ldb, stream_nt);
+  group_walk<T, POLICY, false, false>(stream, nullptr, chunk_meta, Bp, Cv, P, nchunks, k, col_tile, ldb, stream_nt);
+}
+
+template <int T, int POLICY>
+__global__ void __launch_bounds__(256)
+spmm_group_ring_kernel(const unsigned short* __restrict__ stream, const int2* __restrict__ chunk_meta,
+                       const float* __restrict__ Bp, float* __restrict__ Cv, float* __restrict__ P,
+                       int nchunks, int k, int col_tile, int ldb, int stream_nt) {
+  group_walk<T, POLICY, false, true>(stream, nullptr, chunk_meta, Bp, Cv, P, nchunks, k, col_tile, ldb, stream_nt);
 }
 
 // the same walk for matrices whose values do not factor: one fp32 value per entry beside the 16-bit stream,
@@ -184,7 +229,7 @@ __global__ void __launch_bounds__(256)
 spmm_group_weighted_kernel(const unsigned short* __restrict__ stream, const float* __restrict__ vals,
                            const int2* __restrict__ chunk_meta, const float* __restrict__ Bp, float* __restrict__ Cv,
                            float* __restrict__ P, int nchunks, int k, int col_tile, int ldb, int stream_nt) {
-  group_walk<T, POLICY, true>(stream, vals, chunk_meta, Bp, Cv, P, nchunks, k, col_tile, ldb, stream_nt);
+  group_walk<T, POLICY, true, false>(stream, vals, chunk_meta, Bp, Cv, P, nchunks, k, col_tile, ldb, stream_nt);
 }
 
 bool spmm_group_eligible(int k, int ldb, const void* B, const void* C, const void* P) {
@@ -202,6 +247,7 @@ hipError_t launch_spmm_group(const GroupArgs& a, hipStream_t s) {
   const int ldb = a.ldb > 0 ? a.ldb : a.k;
   // streams (2 or 6 bytes per entry) beyond what the L2s and a good part of the Infinity Cache hold are read non-temporally
   const int stream_nt = (size_t)a.nchunks * (size_t)a.T * (a.vals ? 6u : 2u) > ((size_t)64 << 20) ? 1 : 0;
+  const bool ring = a.ring != 0;
   for (int t = 0; t < tiles; ++t) {
 #define GCN_GROUP_REST reinterpret_cast<const int2*>(a.chunk_meta), a.Bp, a.Cv, a.P, a.nchunks, a.k, t, ldb, stream_nt
 #define GCN_GROUP_PICK(KERNEL, TT, ...)                                                                  \
@@ -210,6 +256,7 @@ hipError_t launch_spmm_group(const GroupArgs& a, hipStream_t s) {
       else                          KERNEL<TT, 0><<<dim3(nblocks), dim3(256), 0, s>>>(__VA_ARGS__);
 #define GCN_GROUP_LAUNCH(TT)                                                                             \
       if (a.vals) { GCN_GROUP_PICK(spmm_group_weighted_kernel, TT, a.stream, a.vals, GCN_GROUP_REST) }   \
+      else if (ring) { GCN_GROUP_PICK(spmm_group_ring_kernel, TT, a.stream, GCN_GROUP_REST) }            \
       else        { GCN_GROUP_PICK(spmm_group_kernel, TT, a.stream, GCN_GROUP_REST) }                    \
       break;
     switch (a.T) {

@@ -721,7 +721,7 @@ def test_automatic_slice_count_follows_the_value_factors():
     assert sampled_rows_oracle_err(rowptr, col, val, B, with_values, rows)[0] <= TOL
     u = graphgen.value_factor_from_degrees(deg)
     adj.set_value_factors(u[lo:hi], u)
-    assert adj.has_value_factors and adj.num_slices == 11 and adj.main_kernel(128).startswith("gcn::spmm_group_kernel<")
+    assert adj.has_value_factors and adj.num_slices == 11 and adj.main_kernel(128).startswith("gcn::spmm_group_ring_kernel<")
     value_free = adj.matmul_raw(B)
     assert sampled_rows_oracle_err(rowptr, col, val, B, value_free, rows)[0] <= TOL
     adj.enable_slicing(4)                                       # an explicit count is kept
