@@ -11,11 +11,13 @@
 // Here each 16-lane group (lane = g*16 + f, f = which float4 of the 64-column tile) walks its OWN chunk
 // of the slice-major stream, one entry per step, and owns the complete sum of its current row:
 //   * one global_load_dwordx4 still fetches four feature rows (4 x 256 B), one per group;
-//   * a row end is a bit in the stream (bit 15 of the 16-bit entry) and costs the group ONE 256-byte store
-//     under an EXEC mask — no cross-lane traffic, no row pointers in the kernel at all;
+//   * a row end is a bit in the stream (bit 15 of the 16-bit entry) and costs the group ONE 256-byte write
+//     under an EXEC mask — into its LDS ring, from where four consecutive rows leave with one 64-lane store
+//     (spmm_group_ring_kernel), or straight to memory — no cross-lane reduction, no row pointers in the kernel;
 //   * entries are 16 bits: the column's offset inside its slice (slices <= 32 767 columns); every virtual
 //     row has at least one entry (empty ones get a padding entry that gathers the slice's all-zero row),
-//     so "next row" is pointer arithmetic;
+//     so "next row" is pointer arithmetic; runs of 64 entries are stored lane-major, so a lane fetches its
+//     entries of four blocks with one 8-byte load;
 //   * the byte offset of the gathered row is computed once per entry at load time (one lane = one entry
 //     of its group's 16-entry block) and reaches the group by a DPP row broadcast fused into the address
 //     add: per step one VALU op for the address, one load, two packed adds.
