@@ -631,13 +631,19 @@ int gcn_spmm_plan_set_value_factors(gcn_spmm_plan_t* p, const int32_t* rowptr, c
   p->factors = gcn::Factors{};
   p->col16 = gcn::Col16Stream{};                       // (the value-free streams exist only beside factors)
   p->group = gcn::GroupStream{};
-  if (!u_row && !u_col) return GCN_OK;                              // (null, null): forget the factors
+  if (!u_row && !u_col) {                                           // (null, null): forget the factors;
+    build_sliced_streams(p, (hipStream_t)stream);                   // the sliced plan goes back to its value stream
+    return GCN_OK;
+  }
   if (!u_row || !u_col || !rowptr || (p->nnz > 0 && (!col || !val))) return GCN_ERR_INVALID_ARG;
   if (p->m == 0 || p->nnz == 0 || !gcn::valless_enabled()) return GCN_OK;
   hipStream_t st = (hipStream_t)stream;
   int ok = 0;
   if (gcn::verify_value_factors(rowptr, col, val, u_row, u_col, p->m, &ok, st) != hipSuccess) return GCN_ERR_HIP;
-  if (!ok) return GCN_ERR_INVALID_ARG;                              // some entry is not u_row[r]*u_col[c]
+  if (!ok) {                                                        // some entry is not u_row[r]*u_col[c]
+    build_sliced_streams(p, st);                                    // (the plan keeps working on its value stream)
+    return GCN_ERR_INVALID_ARG;
+  }
   gcn::Factors f;
   if (f.u_row.alloc((size_t)p->m) != hipSuccess || f.u_col_own.alloc((size_t)p->n) != hipSuccess) return GCN_ERR_ALLOC;
   if (hipMemcpyAsync(f.u_row, u_row, sizeof(float) * (size_t)p->m, hipMemcpyDeviceToDevice, st) != hipSuccess ||

@@ -698,6 +698,10 @@ def test_explicit_value_factors_on_a_row_block_with_renumbered_columns():
         adj.set_value_factors(torch.from_numpy(u[lo:hi] * 1.001), torch.from_numpy(u_col))
     assert not adj.has_value_factors                            # a refused hand-over leaves none behind
     assert rel_err(adj.matmul_raw(Bd).cpu().numpy(), Cref) <= TOL
+    adj.set_value_factors(torch.from_numpy(u[lo:hi]), torch.from_numpy(u_col))
+    adj.set_value_factors(None, None)                           # forgotten on request: back to the value stream
+    assert not adj.has_value_factors and adj.main_kernel(128).startswith("gcn::spmm_group_weighted_kernel<")
+    assert rel_err(adj.matmul_raw(Bd).cpu().numpy(), Cref) <= TOL
 
 
 def test_automatic_slice_count_follows_the_value_factors():
