@@ -1,0 +1,68 @@
+"""Randomised stress of the group kernels (spmm_group.hip) — the value-free pass with its LDS ring and the weighted
+pass — over graph shapes that hit their corners: hub rows spanning many chunks, runs of one-entry rows (ring
+overflow: more than four rows end inside one block), empty virtual rows, slices that end up empty, partial last
+column tiles, row-padded and odd-width copies, every epilogue.  Each case against the fp64 oracle; seeds are fixed."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+import gcn_amd
+from util import oracle_spmm, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _graph(seed):
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(300, 6000))
+    style = seed % 4
+    if style == 0:                       # near-regular, moderate degree
+        e = n * int(rng.integers(8, 40))
+        u, v = rng.integers(0, n, e), rng.integers(0, n, e)
+    elif style == 1:                     # a few hubs that see everyone + a sparse rest (rows of 1-3 entries)
+        hubs = rng.choice(n, int(rng.integers(1, 6)), replace=False)
+        u = np.concatenate([np.repeat(hubs, n // 2), rng.integers(0, n, n)])
+        v = np.concatenate([rng.integers(0, n, len(hubs) * (n // 2)), rng.integers(0, n, n)])
+    elif style == 2:                     # power-law-ish
+        w = 1.0 / np.arange(1, n + 1) ** 0.9
+        w /= w.sum()
+        e = n * int(rng.integers(4, 25))
+        u, v = rng.choice(n, e, p=w), rng.integers(0, n, e)
+    else:                                # two blocks: one dense, one almost empty (slices that end up empty)
+        half = n // 2
+        e = half * int(rng.integers(20, 60))
+        u, v = rng.integers(0, half, e), rng.integers(0, half, e)
+    A = sp.coo_matrix((np.ones(len(u)), (u, v)), shape=(n, n))
+    A = (A + A.T).tocsr(); A.setdiag(0); A.eliminate_zeros(); A.data[:] = 1.0
+    A = (A + sp.eye(n)).tocsr()
+    d = np.asarray(A.sum(1)).ravel() ** -0.5
+    A = (sp.diags(d) @ A @ sp.diags(d)).tocsr(); A.sort_indices()
+    return n, A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.astype(np.float32), rng
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_group_kernels_random(seed):
+    n, rowptr, col, val, rng = _graph(seed)
+    d = torch.device("cuda:0")
+    S = int(rng.choice([2, 3, 5, 8, 13, 16]))
+    k = int(rng.choice([36, 64, 100, 128, 41, 192]))
+    weighted = seed % 3 == 2
+    if weighted:
+        val = (val * (1.0 + 0.5 * rng.random(len(val)))).astype(np.float32)      # no longer u[r]*u[c]
+    adj = gcn_amd.CsrAdjacency(torch.from_numpy(rowptr).to(d), torch.from_numpy(col).to(d), torch.from_numpy(val).to(d),
+                               (n, n), slices=S)
+    assert adj.num_slices == S
+    name = adj.main_kernel(k)
+    assert name.startswith("gcn::spmm_group_weighted_kernel<" if weighted else "gcn::spmm_group"), name
+    assert adj.has_value_factors == (not weighted)
+    B = rng.standard_normal((n, k)).astype(np.float32)
+    ref = oracle_spmm(rowptr, col, val, B)
+    Bd = torch.from_numpy(B).to(d)
+    C = adj.matmul_raw(Bd)
+    assert rel_err(C.cpu().numpy(), ref) <= TOL, (seed, n, S, k, weighted)
+    assert torch.equal(C, adj.matmul_raw(Bd))                                    # bitwise reproducible
+    bias = rng.standard_normal(k).astype(np.float32)
+    Ce = adj.matmul_raw(Bd, bias=torch.from_numpy(bias).to(d), relu=True).cpu().numpy()
+    assert rel_err(Ce, np.maximum(ref + bias, 0)) <= TOL, (seed, n, S, k, weighted)
