@@ -71,6 +71,7 @@ int group_store() {                                                             
   return v;
 }
 bool group_ring() { static const bool v = env_on("GCN_AMD_GROUP_RING"); return v; }   // finished rows through the LDS ring (value-free pass)
+bool group_merge_tiles() { static const bool v = env_on("GCN_AMD_GROUP_MERGE_TILES"); return v; }   // all column tiles in one launch
 bool group_weighted_enabled() { static const bool v = env_on("GCN_AMD_GROUP_WEIGHTED"); return v; }   // group kernel for values that do not factor
 bool quad_stream_rows() { static const bool v = env_on("GCN_AMD_QUAD_NT"); return v; }   // sliced pass with values: nt partial-row stores
 int group_chunk() {                                                                     // entries per 16-lane group chunk
@@ -384,6 +385,7 @@ int spmm_impl(gcn_spmm_plan* p, const int32_t* rowptr, const int32_t* col, const
     ga.nchunks = p->group.nchunks; ga.T = p->group.T; ga.k = k; ga.ldb = a.ldb;
     ga.store_policy = gcn::group_store();
     ga.ring = gcn::group_ring() ? 1 : 0;
+    ga.merge_tiles = gcn::group_merge_tiles() ? 1 : 0;
     if (ev0 && hipEventRecord(ev0, st) != hipSuccess) return GCN_ERR_HIP;
     if (gcn::launch_spmm_group(ga, st) != hipSuccess) return GCN_ERR_HIP;
     if (ev1 && hipEventRecord(ev1, st) != hipSuccess) return GCN_ERR_HIP;
@@ -779,6 +781,12 @@ int gcn_spmm_plan_set_blocks_per_cu(gcn_spmm_plan_t* p, int32_t blocks) {
 int32_t gcn_spmm_plan_num_passes(const gcn_spmm_plan_t* p, int32_t k) {
   if (!p || k <= 0) return -1;
   if (p->panels.R > 0 && k > 32) return (k + 63) / 64;
+  if (gcn::group_merge_tiles()) {                      // the group kernels take every tile in one launch
+    int kk = k, ldb = gcn::padded_ldb(p->n, k);
+    if (odd_width_detour(p, k)) { kk = (k + 3) / 4 * 4; ldb = (kk + 31) / 32 * 32; }
+    const bool vl = valless_pays(p, kk, ldb);
+    if (group_launch(p, vl, !vl && weighted_pass(p, kk, ldb))) return 1;
+  }
   const int tile = p->tile_cols ? p->tile_cols : (p->slicing.S > 0 && k > 32 ? 64 : gcn::auto_tile_cols(p->n, k));
   const int vec = gcn::pick_vec(k, tile, nullptr, nullptr, nullptr);   // 16-B aligned operands
   return (k + 64 * vec - 1) / (64 * vec);

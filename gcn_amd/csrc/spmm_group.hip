@@ -79,15 +79,21 @@ template <int T, int POLICY, bool VALS, bool RING>
 __device__ __forceinline__ void
 group_walk(const unsigned short* __restrict__ stream, const float* __restrict__ vals, const int2* __restrict__ chunk_meta,
            const float* __restrict__ Bp, float* __restrict__ Cv, float* __restrict__ P,
-           int nchunks, int k, int col_tile, int ldb, int stream_nt) {
+           int nchunks, int k, int col_tile, int ldb, int stream_nt, int blocks_per_tile) {
   const int lane = threadIdx.x & 63;
   const int wib  = threadIdx.x >> 6;
   const int g    = lane >> 4;
   const int f    = lane & 15;
   const int per_xcd = nchunks >> 3;
-  const int c_in = ((int)(blockIdx.x >> 3) * 4 + wib) * 4;
+  // One launch can cover several 64-column tiles: blocks [t*blocks_per_tile, (t+1)*blocks_per_tile) walk the whole
+  // stream for tile col_tile + t.  Blocks are dispatched in index order, so the next tile starts on the CUs the
+  // previous one's last blocks leave idle (blocks_per_tile % 8 == 0: a block's XCD is blockIdx % 8 either way).
+  const int tile_in_launch = (int)blockIdx.x / blocks_per_tile;
+  const int bx = (int)blockIdx.x - tile_in_launch * blocks_per_tile;
+  col_tile += tile_in_launch;
+  const int c_in = ((bx >> 3) * 4 + wib) * 4;
   if (c_in >= per_xcd) return;                                  // (whole wave: per_xcd % 4 == 0)
-  const int c = (int)(blockIdx.x & 7) * per_xcd + c_in + g;     // this group's chunk
+  const int c = (bx & 7) * per_xcd + c_in + g;                  // this group's chunk
 
   const int fcol = col_tile * 64 + f * 4;
   const bool fok = fcol < k;                                    // (k % 4 == 0: a float4 is all in or all out)
@@ -211,16 +217,16 @@ template <int T, int POLICY>
 __global__ void __launch_bounds__(256)
 spmm_group_kernel(const unsigned short* __restrict__ stream, const int2* __restrict__ chunk_meta,
                   const float* __restrict__ Bp, float* __restrict__ Cv, float* __restrict__ P,
-                  int nchunks, int k, int col_tile, int ldb, int stream_nt) {
-  group_walk<T, POLICY, false, false>(stream, nullptr, chunk_meta, Bp, Cv, P, nchunks, k, col_tile, ldb, stream_nt);
+                  int nchunks, int k, int col_tile, int ldb, int stream_nt, int blocks_per_tile) {
+  group_walk<T, POLICY, false, false>(stream, nullptr, chunk_meta, Bp, Cv, P, nchunks, k, col_tile, ldb, stream_nt, blocks_per_tile);
 }
 
 template <int T, int POLICY>
 __global__ void __launch_bounds__(256)
 spmm_group_ring_kernel(const unsigned short* __restrict__ stream, const int2* __restrict__ chunk_meta,
                        const float* __restrict__ Bp, float* __restrict__ Cv, float* __restrict__ P,
-                       int nchunks, int k, int col_tile, int ldb, int stream_nt) {
-  group_walk<T, POLICY, false, true>(stream, nullptr, chunk_meta, Bp, Cv, P, nchunks, k, col_tile, ldb, stream_nt);
+                       int nchunks, int k, int col_tile, int ldb, int stream_nt, int blocks_per_tile) {
+  group_walk<T, POLICY, false, true>(stream, nullptr, chunk_meta, Bp, Cv, P, nchunks, k, col_tile, ldb, stream_nt, blocks_per_tile);
 }
 
 // the same walk for matrices whose values do not factor: one fp32 value per entry beside the 16-bit stream,
@@ -230,8 +236,8 @@ template <int T, int POLICY>
 __global__ void __launch_bounds__(256)
 spmm_group_weighted_kernel(const unsigned short* __restrict__ stream, const float* __restrict__ vals,
                            const int2* __restrict__ chunk_meta, const float* __restrict__ Bp, float* __restrict__ Cv,
-                           float* __restrict__ P, int nchunks, int k, int col_tile, int ldb, int stream_nt) {
-  group_walk<T, POLICY, true, false>(stream, vals, chunk_meta, Bp, Cv, P, nchunks, k, col_tile, ldb, stream_nt);
+                           float* __restrict__ P, int nchunks, int k, int col_tile, int ldb, int stream_nt, int blocks_per_tile) {
+  group_walk<T, POLICY, true, false>(stream, vals, chunk_meta, Bp, Cv, P, nchunks, k, col_tile, ldb, stream_nt, blocks_per_tile);
 }
 
 bool spmm_group_eligible(int k, int ldb, const void* B, const void* C, const void* P) {
@@ -244,14 +250,19 @@ hipError_t launch_spmm_group(const GroupArgs& a, hipStream_t s) {
   if (a.nchunks <= 0 || a.k <= 0) return hipSuccess;
   if (a.nchunks % 32 != 0 || a.k % 4 != 0) return hipErrorInvalidValue;
   const int per_xcd = a.nchunks / 8;
-  const int nblocks = 8 * ((per_xcd + 15) / 16);
+  int nblocks = 8 * ((per_xcd + 15) / 16);
   const int tiles = (a.k + 63) / 64;
   const int ldb = a.ldb > 0 ? a.ldb : a.k;
   // streams (2 or 6 bytes per entry) beyond what the L2s and a good part of the Infinity Cache hold are read non-temporally
   const int stream_nt = (size_t)a.nchunks * (size_t)a.T * (a.vals ? 6u : 2u) > ((size_t)64 << 20) ? 1 : 0;
   const bool ring = a.ring != 0;
-  for (int t = 0; t < tiles; ++t) {
-#define GCN_GROUP_REST reinterpret_cast<const int2*>(a.chunk_meta), a.Bp, a.Cv, a.P, a.nchunks, a.k, t, ldb, stream_nt
+  // all tiles in ONE launch (merge_tiles): tile t+1 starts on the CUs that tile t's last blocks leave idle
+  const int tiles_per_launch = a.merge_tiles ? tiles : 1;
+  if ((long long)nblocks * tiles_per_launch >= (1LL << 31)) return hipErrorInvalidValue;
+  const int blocks_per_tile = nblocks;
+  nblocks *= tiles_per_launch;
+  for (int t = 0; t < tiles; t += tiles_per_launch) {
+#define GCN_GROUP_REST reinterpret_cast<const int2*>(a.chunk_meta), a.Bp, a.Cv, a.P, a.nchunks, a.k, t, ldb, stream_nt, blocks_per_tile
 #define GCN_GROUP_PICK(KERNEL, TT, ...)                                                                  \
       if (a.store_policy == 1)      KERNEL<TT, 1><<<dim3(nblocks), dim3(256), 0, s>>>(__VA_ARGS__);     \
       else if (a.store_policy == 2) KERNEL<TT, 2><<<dim3(nblocks), dim3(256), 0, s>>>(__VA_ARGS__);     \

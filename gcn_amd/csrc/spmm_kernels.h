@@ -78,6 +78,7 @@ struct GroupArgs {
   float* P;                      // partial slab [2*nchunks x k]
   int nchunks, T, k, ldb;        // T = entries per chunk (of ONE 16-lane group), ldb = row stride of Bp (0 = k)
   int store_policy = 2;          // partial-row stores: 0 plain, 1 sc1 (write-through), 2 nt (streaming)
+  int merge_tiles = 1;           // every 64-column tile in one launch (tile t+1 fills the CUs tile t's tail leaves idle)
   int ring = 1;                  // value-free pass: finished rows leave through the LDS ring, four at a time (spmm_group_ring_kernel)
 };
 bool spmm_group_eligible(int k, int ldb, const void* B, const void* C, const void* P);
