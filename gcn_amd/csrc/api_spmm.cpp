@@ -84,7 +84,8 @@ double panel_mfma_density() {                                                   
                                return d > 0.0 && d <= 1.0 ? d : 0.25; }();
   return v;
 }
-int slice_min_k() { static const int v = env_int("GCN_AMD_SLICE_MIN_K", 33); return v; }  // smallest k the sliced copy is used for
+int slice_min_k() { static const int v = env_int("GCN_AMD_SLICE_MIN_K", 33); return v; }  // smallest k the sliced copy is used for (four-per-gather kernel)
+int group_min_k() { static const int v = env_int("GCN_AMD_GROUP_MIN_K", 12); return v; }  // ... when the group kernels walk it
 
 // Expected 128-byte cache lines one gathered feature row costs, summed over its 64-column tiles, when B's
 // rows are `ld` floats apart (the row start offsets cycle through the multiples of gcd(4*ld, 128)).
@@ -209,7 +210,20 @@ int grow(gcn::DevBuf<T>& buf, size_t count) {
   return buf.grow(count) == hipSuccess ? GCN_OK : GCN_ERR_ALLOC;
 }
 
-bool sliced_for(const gcn_spmm_plan* p, int k) { return p->slicing.S > 0 && p->nnz > 0 && k >= gcn::slice_min_k(); }
+// Is a k-wide SpMM of this plan launched on the sliced copy?  The four-per-gather kernel pays from k = 33 (narrower
+// rows gather 128 B or less per non-zero: the partial rows cost more than the L2 hits buy, 2.12 vs 2.02 ms at
+// k = 32).  The group kernels pay from k = 12: their 64-column pass costs the same whatever k is, and beats the
+// unsliced kernels there (Reddit-shaped, whole SpMM, profiles/r02zzg_narrow_widths_sliced.log: k = 12 / 16 / 20 /
+// 32: 1.49 / 1.36 / 1.60 / 1.58 -> 1.23 / 1.02 / 1.23 / 1.10 ms; k = 8 a tie, k = 4 loses) — provided the width
+// reaches them: a multiple of 4, or wide enough for the k' = ceil(k/4)*4 detour.
+bool sliced_for(const gcn_spmm_plan* p, int k) {
+  if (p->slicing.S <= 0 || p->nnz <= 0) return false;
+  if (k >= gcn::slice_min_k()) return true;
+  if (!p->group.ready() || p->panels.R != 0 || k < gcn::group_min_k()) return false;
+  if (k % 4 == 0) return true;
+  const int kp = (k + 3) / 4 * 4, ldb = (kp + 31) / 32 * 32;         // (the conditions of odd_width_detour)
+  return k > 16 && p->gather_width != 1 && gcn::pad_b_enabled() && (long long)sizeof(float) * p->n * ldb <= (768LL << 20);
+}
 
 // would the sliced launch of a k-wide SpMM run a value-free kernel (and is the scaled copy of B worth it)?
 bool valless_pays(const gcn_spmm_plan* p, int k, int ldb) {
@@ -302,9 +316,7 @@ int spmm_impl(gcn_spmm_plan* p, const int32_t* rowptr, const int32_t* col, const
   a.chunk_row = p->chunk_row; a.bias = bias; a.relu = relu;
   a.nchunks = p->nchunks; a.T = p->T; a.m = p->m; a.nnz = p->nnz; a.k = k; a.n = p->n;
   a.nnz_dev = nullptr; a.nchunks_grid = p->nchunks;
-  // narrow feature widths (k <= 32, the GCN hidden/class sizes) gather 128 B or less per
-  // non-zero: there the extra partial rows cost more than the L2 hits buy (measured 2.12 vs
-  // 2.02 ms at k = 32), so the sliced copy is used for k > 32 only
+  // (which widths run on the sliced copy: sliced_for)
   const bool sliced = sliced_for(p, k);
   // Feature rows that are not a whole number of 128-byte cache lines straddle lines: a gathered row
   // then costs up to one extra L2 request per tile.  Where that matters (padded_ldb) B is first re-laid
