@@ -72,6 +72,7 @@ int group_store() {                                                             
 }
 bool group_ring() { static const bool v = env_on("GCN_AMD_GROUP_RING"); return v; }   // finished rows through the LDS ring (value-free pass)
 bool group_merge_tiles() { static const bool v = env_on("GCN_AMD_GROUP_MERGE_TILES"); return v; }   // all column tiles in one launch
+bool group8_enabled() { static const bool v = env_on("GCN_AMD_GROUP8"); return v; }   // k <= 32: eight 8-lane row engines per wave
 bool group_weighted_enabled() { static const bool v = env_on("GCN_AMD_GROUP_WEIGHTED"); return v; }   // group kernel for values that do not factor
 bool quad_stream_rows() { static const bool v = env_on("GCN_AMD_QUAD_NT"); return v; }   // sliced pass with values: nt partial-row stores
 int group_chunk() {                                                                     // entries per 16-lane group chunk
@@ -398,6 +399,7 @@ int spmm_impl(gcn_spmm_plan* p, const int32_t* rowptr, const int32_t* col, const
     ga.store_policy = gcn::group_store();
     ga.ring = gcn::group_ring() ? 1 : 0;
     ga.merge_tiles = gcn::group_merge_tiles() ? 1 : 0;
+    ga.narrow8 = gcn::group8_enabled() ? 1 : 0;
     if (ev0 && hipEventRecord(ev0, st) != hipSuccess) return GCN_ERR_HIP;
     if (gcn::launch_spmm_group(ga, st) != hipSuccess) return GCN_ERR_HIP;
     if (ev1 && hipEventRecord(ev1, st) != hipSuccess) return GCN_ERR_HIP;
@@ -825,7 +827,10 @@ int gcn_spmm_plan_main_kernel(const gcn_spmm_plan_t* p, int32_t k, int32_t epilo
   }
   a.col16 = a.valless && p->col16.ready();
   if (a.valless && group_pass(p)) {
-    snprintf(buf, (size_t)buflen, "gcn::spmm_group%s_kernel<%d, %d>", gcn::group_ring() ? "_ring" : "", p->group.T, gcn::group_store());
+    if (gcn::group8_enabled() && a.k <= 32 && p->group.nchunks % 64 == 0)
+      snprintf(buf, (size_t)buflen, "gcn::spmm_group8_kernel<%d>", p->group.T);
+    else
+      snprintf(buf, (size_t)buflen, "gcn::spmm_group%s_kernel<%d, %d>", gcn::group_ring() ? "_ring" : "", p->group.T, gcn::group_store());
     return GCN_OK;
   }
   if (!a.valless && weighted_pass(p, a.k, a.ldb > 0 ? a.ldb : a.k)) {

@@ -240,10 +240,132 @@ spmm_group_weighted_kernel(const unsigned short* __restrict__ stream, const floa
   group_walk<T, POLICY, true, false>(stream, vals, chunk_meta, Bp, Cv, P, nchunks, k, col_tile, ldb, stream_nt, blocks_per_tile);
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// k <= 32: EIGHT independent 8-lane row engines per wave (lane = g*8 + f, f = which float4 of the 32-column tile).
+// A gather instruction then fetches eight feature rows of 128 bytes instead of four of 256, so a non-zero costs half
+// the addresser time of the 64-column pass it would otherwise ride in with half its lanes idle.  Same stream, same
+// lane-major runs of 64 entries (a lane of an 8-lane group reads its entries of the run's eight 8-entry blocks as two
+// 8-byte words: u16 4f.. and 32+4f..), same chunk_meta / partial slab / fix list; a wave owns eight consecutive
+// chunks.  The DPP broadcasts still work on rows of 16 lanes = two groups: the upper group of a row takes its
+// entry from a copy rotated by eight lanes.  Two 8-entry blocks are in flight together (sixteen gathers).
+// Value-free only, non-temporal stores, finished rows stored by their group at once.
+template <int UU>
+__device__ __forceinline__ int row_ror8_bcast(int v, int vrot, bool upper) {   // entry UU of THIS lane's 8-lane group
+  const int lo = row_bcast<UU>(v), hi = row_bcast<UU>(vrot);
+  return upper ? hi : lo;
+}
+
+template <int T>
+__global__ void __launch_bounds__(256)
+spmm_group8_kernel(const unsigned short* __restrict__ stream, const int2* __restrict__ chunk_meta,
+                   const float* __restrict__ Bp, float* __restrict__ Cv, float* __restrict__ P,
+                   int nchunks, int k, int ldb, int stream_nt) {
+  static_assert(T % 64 == 0, "a chunk is whole runs of 64 entries");
+  const int lane = threadIdx.x & 63;
+  const int wib  = threadIdx.x >> 6;
+  const int g    = lane >> 3;
+  const int f    = lane & 7;
+  const bool upper = (lane & 8) != 0;                           // the upper group of its 16-lane DPP row
+  const int per_xcd = nchunks >> 3;
+  const int c_in = ((int)(blockIdx.x >> 3) * 4 + wib) * 8;
+  if (c_in >= per_xcd) return;                                  // (whole wave: per_xcd % 8 == 0)
+  const int c = (int)(blockIdx.x & 7) * per_xcd + c_in + g;     // this group's chunk
+
+  const int fcol = f * 4;
+  const bool fok = fcol < k;
+  const unsigned row_bytes = (unsigned)ldb * 4u;
+  const unsigned foff = (unsigned)(fok ? fcol : 0) * 4u;
+  const char* __restrict__ Bb = reinterpret_cast<const char*>(Bp);
+  const size_t kk = (size_t)k;
+
+  const int2 meta = chunk_meta[c];
+  const int vrow = meta.x >> 1;
+  const bool head = meta.x & 1;
+  const int base = meta.y;
+  float* ptr  = head ? P + (size_t)(2 * c) * kk + fcol : Cv + (size_t)vrow * kk + fcol;
+  float* nptr = Cv + (size_t)(vrow + 1) * kk + fcol;
+  bool first = true;
+
+  typedef unsigned int u32x2_g8 __attribute__((ext_vector_type(2)));
+  const u32x2_g8* __restrict__ sp = reinterpret_cast<const u32x2_g8*>(stream + (size_t)c * T);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  // words of the current run: w0 = entries of the even 8-entry blocks (0, 2, 4, 6), w1 = of the odd ones
+  u32x2_g8 w0 = stream_nt ? __builtin_nontemporal_load(sp + f) : sp[f];
+  u32x2_g8 w1 = stream_nt ? __builtin_nontemporal_load(sp + 8 + f) : sp[8 + f];
+  u32x2_g8 w0_nx = w0, w1_nx = w1;
+  unsigned fl1 = 0;
+#pragma unroll 1
+  for (int d = 0; d < T / 16; ++d) {                            // two 8-entry blocks (2d, 2d+1 of the chunk) per turn
+    const int j = d & 3;                                        // ... the j-th pair of the current run
+    if (j == 0 && d + 4 < T / 16) {                             // the next run, a whole run ahead of its use
+      const u32x2_g8* nx = sp + (d / 4 + 1) * 16;
+      w0_nx = stream_nt ? __builtin_nontemporal_load(nx + f) : nx[f];
+      w1_nx = stream_nt ? __builtin_nontemporal_load(nx + 8 + f) : nx[8 + f];
+    }
+    const unsigned e0 = ((j & 2 ? w0.y : w0.x) >> (16 * (j & 1))) & 0xFFFFu;
+    const unsigned e1 = ((j & 2 ? w1.y : w1.x) >> (16 * (j & 1))) & 0xFFFFu;
+    if (j == 3) { w0 = w0_nx; w1 = w1_nx; }
+    const int ro0 = (int)(__umul24((e0 & 0x7FFFu) + (unsigned)base, row_bytes));
+    const int ro1 = (int)(__umul24((e1 & 0x7FFFu) + (unsigned)base, row_bytes));
+    const int ro0r = __builtin_amdgcn_mov_dpp(ro0, 0x128, 0xf, 0xf, true);   // row_ror:8 — lane l <- lane (l + 8) % 16 of its row
+    const int ro1r = __builtin_amdgcn_mov_dpp(ro1, 0x128, 0xf, 0xf, true);
+    const unsigned fl0 = e0 >> 15;
+    fl1 = e1 >> 15;
+    const int fl0r = __builtin_amdgcn_mov_dpp((int)fl0, 0x128, 0xf, 0xf, true);
+    const int fl1r = __builtin_amdgcn_mov_dpp((int)fl1, 0x128, 0xf, 0xf, true);
+    float4 b[16];
+#define GCN_G8_ALL(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7)
+#define GCN_G8_GATHER0(UU) \
+    b[UU] = *reinterpret_cast<const float4*>(Bb + (size_t)((unsigned)row_ror8_bcast<UU>(ro0, ro0r, upper) + foff));
+#define GCN_G8_GATHER1(UU) \
+    b[8 + UU] = *reinterpret_cast<const float4*>(Bb + (size_t)((unsigned)row_ror8_bcast<UU>(ro1, ro1r, upper) + foff));
+    GCN_G8_ALL(GCN_G8_GATHER0)
+    GCN_G8_ALL(GCN_G8_GATHER1)
+#undef GCN_G8_GATHER0
+#undef GCN_G8_GATHER1
+    const unsigned long long ends0 = __ballot(fl0 != 0);        // bit g*8+u: entry u of group g (first block) ends a row
+    const unsigned long long ends1 = __ballot(fl1 != 0);
+#define GCN_G8_ADD(I) acc.x += b[I].x; acc.y += b[I].y; acc.z += b[I].z; acc.w += b[I].w;
+    if ((ends0 | ends1) == 0ull) {
+      GCN_G8_ADD(0) GCN_G8_ADD(1) GCN_G8_ADD(2) GCN_G8_ADD(3) GCN_G8_ADD(4) GCN_G8_ADD(5) GCN_G8_ADD(6) GCN_G8_ADD(7)
+      GCN_G8_ADD(8) GCN_G8_ADD(9) GCN_G8_ADD(10) GCN_G8_ADD(11) GCN_G8_ADD(12) GCN_G8_ADD(13) GCN_G8_ADD(14) GCN_G8_ADD(15)
+    } else {
+#define GCN_G8_STEP(UU, I, ENDS, FL, FLR)                                                           \
+      GCN_G8_ADD(I)                                                                                 \
+      if (ENDS & (0x0101010101010101ull << UU)) {                /* some group ends a row here */    \
+        if (row_ror8_bcast<UU>((int)FL, FLR, upper)) {                                              \
+          if (fok) store_row_piece<2>(ptr, acc);                                                    \
+          acc = make_float4(0.f, 0.f, 0.f, 0.f);                                                    \
+          ptr = nptr; nptr += kk; first = false;                                                    \
+        }                                                                                           \
+      }
+#define GCN_G8_STEP0(UU) GCN_G8_STEP(UU, UU, ends0, fl0, fl0r)
+#define GCN_G8_STEP1(UU) GCN_G8_STEP(UU, 8 + UU, ends1, fl1, fl1r)
+      GCN_G8_ALL(GCN_G8_STEP0)
+      GCN_G8_ALL(GCN_G8_STEP1)
+#undef GCN_G8_STEP0
+#undef GCN_G8_STEP1
+#undef GCN_G8_STEP
+    }
+#undef GCN_G8_ADD
+#undef GCN_G8_ALL
+  }
+  // the row piece that sticks out of the chunk's end (the chunk's last entry — entry 7 of its last block — did not end its row)
+  if (!row_ror8_bcast<7>((int)fl1, __builtin_amdgcn_mov_dpp((int)fl1, 0x128, 0xf, 0xf, true), upper)) {
+    float* dst = (head && first) ? ptr : P + (size_t)(2 * c + 1) * kk + fcol;
+    if (fok) store_row_piece<2>(dst, acc);
+  }
+}
+
 bool spmm_group_eligible(int k, int ldb, const void* B, const void* C, const void* P) {
   const uintptr_t al = (uintptr_t)B | (uintptr_t)C | (uintptr_t)P;
   if (ldb <= 0) ldb = k;
   return k % 4 == 0 && ldb % 4 == 0 && (al & 15) == 0 && ldb * 4 < (1 << 24);
+}
+
+// k <= 32, value-free, whole waves of eight chunks per XCD: the eight-engine kernel takes the launch
+bool spmm_group8_applies(const GroupArgs& a) {
+  return a.narrow8 && !a.vals && a.k <= 32 && a.k % 4 == 0 && a.nchunks % 64 == 0;
 }
 
 hipError_t launch_spmm_group(const GroupArgs& a, hipStream_t s) {
@@ -253,6 +375,19 @@ hipError_t launch_spmm_group(const GroupArgs& a, hipStream_t s) {
   int nblocks = 8 * ((per_xcd + 15) / 16);
   const int tiles = (a.k + 63) / 64;
   const int ldb = a.ldb > 0 ? a.ldb : a.k;
+  if (spmm_group8_applies(a)) {                        // k <= 32: eight 8-lane row engines per wave
+    const int stream_nt8 = (size_t)a.nchunks * (size_t)a.T * 2u > ((size_t)64 << 20) ? 1 : 0;
+    const int nb8 = 8 * ((per_xcd + 31) / 32);
+    const int2* meta = reinterpret_cast<const int2*>(a.chunk_meta);
+    switch (a.T) {
+      case 256:  spmm_group8_kernel<256><<<dim3(nb8), dim3(256), 0, s>>>(a.stream, meta, a.Bp, a.Cv, a.P, a.nchunks, a.k, ldb, stream_nt8); break;
+      case 512:  spmm_group8_kernel<512><<<dim3(nb8), dim3(256), 0, s>>>(a.stream, meta, a.Bp, a.Cv, a.P, a.nchunks, a.k, ldb, stream_nt8); break;
+      case 1024: spmm_group8_kernel<1024><<<dim3(nb8), dim3(256), 0, s>>>(a.stream, meta, a.Bp, a.Cv, a.P, a.nchunks, a.k, ldb, stream_nt8); break;
+      case 2048: spmm_group8_kernel<2048><<<dim3(nb8), dim3(256), 0, s>>>(a.stream, meta, a.Bp, a.Cv, a.P, a.nchunks, a.k, ldb, stream_nt8); break;
+      default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+  }
   // streams (2 or 6 bytes per entry) beyond what the L2s and a good part of the Infinity Cache hold are read non-temporally
   const int stream_nt = (size_t)a.nchunks * (size_t)a.T * (a.vals ? 6u : 2u) > ((size_t)64 << 20) ? 1 : 0;
   const bool ring = a.ring != 0;

@@ -78,11 +78,13 @@ struct GroupArgs {
   float* P;                      // partial slab [2*nchunks x k]
   int nchunks, T, k, ldb;        // T = entries per chunk (of ONE 16-lane group), ldb = row stride of Bp (0 = k)
   int store_policy = 2;          // partial-row stores: 0 plain, 1 sc1 (write-through), 2 nt (streaming)
+  int narrow8 = 1;               // k <= 32 on the eight-engine kernel (spmm_group8_kernel) when nchunks % 64 == 0
   int merge_tiles = 1;           // every 64-column tile in one launch (tile t+1 fills the CUs tile t's tail leaves idle)
   int ring = 1;                  // value-free pass: finished rows leave through the LDS ring, four at a time (spmm_group_ring_kernel)
 };
 bool spmm_group_eligible(int k, int ldb, const void* B, const void* C, const void* P);
 hipError_t launch_spmm_group(const GroupArgs& a, hipStream_t s);
+bool spmm_group8_applies(const GroupArgs& a);
 // the slice-major 15-bit stream the group kernel walks (S slices of width w = ceil(n/S) <= 32767): every virtual
 // row gets >= 1 entry, every slice is padded to whole chunks and the total to a multiple of 32 chunks with
 // entries that gather the slice's zero row.  Outputs: vrowptr_g [S*m+1] (caller-allocated; the fix-up pass needs
