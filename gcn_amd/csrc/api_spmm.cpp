@@ -828,7 +828,7 @@ int gcn_spmm_plan_main_kernel(const gcn_spmm_plan_t* p, int32_t k, int32_t epilo
   a.col16 = a.valless && p->col16.ready();
   if (a.valless && group_pass(p)) {
     if (gcn::group8_enabled() && a.k <= 32 && p->group.nchunks % 64 == 0)
-      snprintf(buf, (size_t)buflen, "gcn::spmm_group8_kernel<%d>", p->group.T);
+      snprintf(buf, (size_t)buflen, "gcn::spmm_group8_kernel<%d, %s>", p->group.T, gcn::group_ring() ? "true" : "false");
     else
       snprintf(buf, (size_t)buflen, "gcn::spmm_group%s_kernel<%d, %d>", gcn::group_ring() ? "_ring" : "", p->group.T, gcn::group_store());
     return GCN_OK;

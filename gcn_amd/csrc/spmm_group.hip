@@ -248,14 +248,14 @@ spmm_group_weighted_kernel(const unsigned short* __restrict__ stream, const floa
 // 8-byte words: u16 4f.. and 32+4f..), same chunk_meta / partial slab / fix list; a wave owns eight consecutive
 // chunks.  The DPP broadcasts still work on rows of 16 lanes = two groups: the upper group of a row takes its
 // entry from a copy rotated by eight lanes.  Two 8-entry blocks are in flight together (sixteen gathers).
-// Value-free only, non-temporal stores, finished rows stored by their group at once.
+// Value-free only, non-temporal stores.
 template <int UU>
 __device__ __forceinline__ int row_ror8_bcast(int v, int vrot, bool upper) {   // entry UU of THIS lane's 8-lane group
   const int lo = row_bcast<UU>(v), hi = row_bcast<UU>(vrot);
   return upper ? hi : lo;
 }
 
-template <int T>
+template <int T, bool RING>
 __global__ void __launch_bounds__(256)
 spmm_group8_kernel(const unsigned short* __restrict__ stream, const int2* __restrict__ chunk_meta,
                    const float* __restrict__ Bp, float* __restrict__ Cv, float* __restrict__ P,
@@ -285,6 +285,21 @@ spmm_group8_kernel(const unsigned short* __restrict__ stream, const int2* __rest
   float* ptr  = head ? P + (size_t)(2 * c) * kk + fcol : Cv + (size_t)vrow * kk + fcol;
   float* nptr = Cv + (size_t)(vrow + 1) * kk + fcol;
   bool first = true;
+  // RING: finished rows wait in LDS, eight slots per group, and leave eight at a time — consecutive rows of ONE group,
+  // written by the whole wave with one 64-lane store (as spmm_group_ring_kernel; here a row is 128 bytes)
+  __shared__ f32x4 ring[RING ? 4 : 1][8][8][8];
+  int ring_n = 0;
+  float* ring_base = nullptr;
+#define GCN_G8_DRAIN(G2, ROWS)                                                                      \
+  {                                                                                                 \
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(uintptr_t)ring_base, 8 * G2);     \
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)((uintptr_t)ring_base >> 32), 8 * G2); \
+    float* b0 = reinterpret_cast<float*>(((uintptr_t)hi << 32) | lo);                              \
+    const f32x4 rv = ring[wib][G2][lane >> 3][f];                                                   \
+    if (fok && (lane >> 3) < (ROWS))                                                                \
+      store_row_piece<2>(b0 + (size_t)(lane >> 3) * kk + f * 4, make_float4(rv.x, rv.y, rv.z, rv.w)); \
+    if (g == G2) ring_n = 0;                                                                        \
+  }
 
   typedef unsigned int u32x2_g8 __attribute__((ext_vector_type(2)));
   const u32x2_g8* __restrict__ sp = reinterpret_cast<const u32x2_g8*>(stream + (size_t)c * T);
@@ -334,7 +349,11 @@ spmm_group8_kernel(const unsigned short* __restrict__ stream, const int2* __rest
       GCN_G8_ADD(I)                                                                                 \
       if (ENDS & (0x0101010101010101ull << UU)) {                /* some group ends a row here */    \
         if (row_ror8_bcast<UU>((int)FL, FLR, upper)) {                                              \
-          if (fok) store_row_piece<2>(ptr, acc);                                                    \
+          if (RING && !(first && head) && ring_n < 8) {                                             \
+            if (fok) ring[wib][g][ring_n][f] = f32x4{acc.x, acc.y, acc.z, acc.w};                   \
+            if (ring_n == 0) ring_base = ptr;                                                       \
+            ++ring_n;                                                                               \
+          } else if (fok) store_row_piece<2>(ptr, acc);                                             \
           acc = make_float4(0.f, 0.f, 0.f, 0.f);                                                    \
           ptr = nptr; nptr += kk; first = false;                                                    \
         }                                                                                           \
@@ -346,10 +365,35 @@ spmm_group8_kernel(const unsigned short* __restrict__ stream, const int2* __rest
 #undef GCN_G8_STEP0
 #undef GCN_G8_STEP1
 #undef GCN_G8_STEP
+      if constexpr (RING) {
+        const unsigned long long full = __ballot(ring_n == 8);
+        if (full) {
+          if (full & (1ull << 0))  GCN_G8_DRAIN(0, 8)
+          if (full & (1ull << 8))  GCN_G8_DRAIN(1, 8)
+          if (full & (1ull << 16)) GCN_G8_DRAIN(2, 8)
+          if (full & (1ull << 24)) GCN_G8_DRAIN(3, 8)
+          if (full & (1ull << 32)) GCN_G8_DRAIN(4, 8)
+          if (full & (1ull << 40)) GCN_G8_DRAIN(5, 8)
+          if (full & (1ull << 48)) GCN_G8_DRAIN(6, 8)
+          if (full & (1ull << 56)) GCN_G8_DRAIN(7, 8)
+        }
+      }
     }
 #undef GCN_G8_ADD
 #undef GCN_G8_ALL
   }
+  if constexpr (RING) {                                         // what is left in the rings
+    const unsigned long long some = __ballot(ring_n > 0);
+    if (some & (1ull << 0))  GCN_G8_DRAIN(0, __builtin_amdgcn_readlane(ring_n, 0))
+    if (some & (1ull << 8))  GCN_G8_DRAIN(1, __builtin_amdgcn_readlane(ring_n, 8))
+    if (some & (1ull << 16)) GCN_G8_DRAIN(2, __builtin_amdgcn_readlane(ring_n, 16))
+    if (some & (1ull << 24)) GCN_G8_DRAIN(3, __builtin_amdgcn_readlane(ring_n, 24))
+    if (some & (1ull << 32)) GCN_G8_DRAIN(4, __builtin_amdgcn_readlane(ring_n, 32))
+    if (some & (1ull << 40)) GCN_G8_DRAIN(5, __builtin_amdgcn_readlane(ring_n, 40))
+    if (some & (1ull << 48)) GCN_G8_DRAIN(6, __builtin_amdgcn_readlane(ring_n, 48))
+    if (some & (1ull << 56)) GCN_G8_DRAIN(7, __builtin_amdgcn_readlane(ring_n, 56))
+  }
+#undef GCN_G8_DRAIN
   // the row piece that sticks out of the chunk's end (the chunk's last entry — entry 7 of its last block — did not end its row)
   if (!row_ror8_bcast<7>((int)fl1, __builtin_amdgcn_mov_dpp((int)fl1, 0x128, 0xf, 0xf, true), upper)) {
     float* dst = (head && first) ? ptr : P + (size_t)(2 * c + 1) * kk + fcol;
@@ -380,10 +424,18 @@ hipError_t launch_spmm_group(const GroupArgs& a, hipStream_t s) {
     const int nb8 = 8 * ((per_xcd + 31) / 32);
     const int2* meta = reinterpret_cast<const int2*>(a.chunk_meta);
     switch (a.T) {
-      case 256:  spmm_group8_kernel<256><<<dim3(nb8), dim3(256), 0, s>>>(a.stream, meta, a.Bp, a.Cv, a.P, a.nchunks, a.k, ldb, stream_nt8); break;
-      case 512:  spmm_group8_kernel<512><<<dim3(nb8), dim3(256), 0, s>>>(a.stream, meta, a.Bp, a.Cv, a.P, a.nchunks, a.k, ldb, stream_nt8); break;
-      case 1024: spmm_group8_kernel<1024><<<dim3(nb8), dim3(256), 0, s>>>(a.stream, meta, a.Bp, a.Cv, a.P, a.nchunks, a.k, ldb, stream_nt8); break;
-      case 2048: spmm_group8_kernel<2048><<<dim3(nb8), dim3(256), 0, s>>>(a.stream, meta, a.Bp, a.Cv, a.P, a.nchunks, a.k, ldb, stream_nt8); break;
+      case 256:  if (a.ring) spmm_group8_kernel<256, true><<<dim3(nb8), dim3(256), 0, s>>>(a.stream, meta, a.Bp, a.Cv, a.P, a.nchunks, a.k, ldb, stream_nt8);
+                 else        spmm_group8_kernel<256, false><<<dim3(nb8), dim3(256), 0, s>>>(a.stream, meta, a.Bp, a.Cv, a.P, a.nchunks, a.k, ldb, stream_nt8);
+                 break;
+      case 512:  if (a.ring) spmm_group8_kernel<512, true><<<dim3(nb8), dim3(256), 0, s>>>(a.stream, meta, a.Bp, a.Cv, a.P, a.nchunks, a.k, ldb, stream_nt8);
+                 else        spmm_group8_kernel<512, false><<<dim3(nb8), dim3(256), 0, s>>>(a.stream, meta, a.Bp, a.Cv, a.P, a.nchunks, a.k, ldb, stream_nt8);
+                 break;
+      case 1024: if (a.ring) spmm_group8_kernel<1024, true><<<dim3(nb8), dim3(256), 0, s>>>(a.stream, meta, a.Bp, a.Cv, a.P, a.nchunks, a.k, ldb, stream_nt8);
+                 else        spmm_group8_kernel<1024, false><<<dim3(nb8), dim3(256), 0, s>>>(a.stream, meta, a.Bp, a.Cv, a.P, a.nchunks, a.k, ldb, stream_nt8);
+                 break;
+      case 2048: if (a.ring) spmm_group8_kernel<2048, true><<<dim3(nb8), dim3(256), 0, s>>>(a.stream, meta, a.Bp, a.Cv, a.P, a.nchunks, a.k, ldb, stream_nt8);
+                 else        spmm_group8_kernel<2048, false><<<dim3(nb8), dim3(256), 0, s>>>(a.stream, meta, a.Bp, a.Cv, a.P, a.nchunks, a.k, ldb, stream_nt8);
+                 break;
       default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
