@@ -780,6 +780,30 @@ def test_group_kernel_value_free_sliced_pass(S):
     assert np.all(np.isnan(C[np.asarray((A[:, [bad[0]]] != 0).sum(1)).ravel() > 0, 5]))
 
 
+@pytest.mark.parametrize("S", [2, 8, 15])
+def test_narrow_widths_on_the_eight_engine_kernel(S):
+    """k <= 32 on a value-free sliced plan runs spmm_group8_kernel (eight 8-lane row engines per wave, 8-slot LDS
+    ring); hub rows cross many chunks, bias/ReLU ride in the slice reduction, results are bitwise reproducible"""
+    n = 9000
+    rowptr, col, val = _hub_graph(n, 700000, hubs=(5, 4000, 8999), seed=31 + S)
+    rng = np.random.default_rng(S)
+    adj = _adj(rowptr, col, val, n, n, slices=S)
+    assert adj.num_slices == S and adj.has_value_factors
+    for k in (12, 16, 20, 24, 28, 32, 17, 30, 31):
+        assert adj.main_kernel(k).startswith("gcn::spmm_group8_kernel<"), (k, adj.main_kernel(k))
+        B = rng.standard_normal((n, k)).astype(np.float32)
+        bias = rng.standard_normal(k).astype(np.float32)
+        Bd = torch.from_numpy(B).to(_dev())
+        Cref = oracle_spmm(rowptr, col, val, B)
+        C = adj.matmul_raw(Bd)
+        assert rel_err(C.cpu().numpy(), Cref) <= TOL, k
+        assert torch.equal(C, adj.matmul_raw(Bd))
+        Ce = adj.matmul_raw(Bd, bias=torch.from_numpy(bias).to(_dev()), relu=True).cpu().numpy()
+        assert rel_err(Ce, np.maximum(Cref + bias, 0)) <= TOL, k
+    assert adj.main_kernel(36).startswith("gcn::spmm_group_ring_kernel<")
+    assert not adj.main_kernel(8).startswith("gcn::spmm_group")
+
+
 def test_value_free_pass_with_slices_wider_than_the_15_bit_stream():
     """slices of more than 32 767 columns cannot use the group kernel's 15-bit entries: the value-free pass then
     runs the four-per-gather kernel on its 16-bit column stream (<= 65 535 columns per slice, <= 8 slices)"""

@@ -66,3 +66,29 @@ def test_group_kernels_random(seed):
     bias = rng.standard_normal(k).astype(np.float32)
     Ce = adj.matmul_raw(Bd, bias=torch.from_numpy(bias).to(d), relu=True).cpu().numpy()
     assert rel_err(Ce, np.maximum(ref + bias, 0)) <= TOL, (seed, n, S, k, weighted)
+
+
+@pytest.mark.parametrize("seed", range(32))
+def test_group8_kernel_random(seed):
+    """k <= 32 on a value-free sliced plan: eight 8-lane row engines per wave (spmm_group8_kernel), LDS ring of eight
+    rows per group; widths that are not a multiple of 4 ride the k' detour into the same kernel; k = 8 stays off it."""
+    n, rowptr, col, val, rng = _graph(seed + 100)
+    d = torch.device("cuda:0")
+    S = int(rng.choice([2, 4, 8, 15]))
+    k = int(rng.choice([12, 16, 20, 24, 28, 32, 17, 30]))
+    adj = gcn_amd.CsrAdjacency(torch.from_numpy(rowptr).to(d), torch.from_numpy(col).to(d), torch.from_numpy(val).to(d),
+                               (n, n), slices=S)
+    assert adj.num_slices == S and adj.has_value_factors
+    name = adj.main_kernel(k)
+    if len(col) // n >= 48:                                      # (below: the weighted pass, see valless_pays)
+        assert name.startswith("gcn::spmm_group8_kernel<"), (name, k)
+    assert not adj.main_kernel(8).startswith("gcn::spmm_group")
+    B = rng.standard_normal((n, k)).astype(np.float32)
+    ref = oracle_spmm(rowptr, col, val, B)
+    Bd = torch.from_numpy(B).to(d)
+    C = adj.matmul_raw(Bd)
+    assert rel_err(C.cpu().numpy(), ref) <= TOL, (seed, n, S, k, name)
+    assert torch.equal(C, adj.matmul_raw(Bd))
+    bias = rng.standard_normal(k).astype(np.float32)
+    Ce = adj.matmul_raw(Bd, bias=torch.from_numpy(bias).to(d), relu=True).cpu().numpy()
+    assert rel_err(Ce, np.maximum(ref + bias, 0)) <= TOL, (seed, n, S, k, name)
