@@ -834,7 +834,8 @@ int gcn_spmm_plan_main_kernel(const gcn_spmm_plan_t* p, int32_t k, int32_t epilo
     return GCN_OK;
   }
   if (!a.valless && weighted_pass(p, a.k, a.ldb > 0 ? a.ldb : a.k)) {
-    snprintf(buf, (size_t)buflen, "gcn::spmm_group_weighted_kernel<%d, %d>", p->group.T, gcn::group_store());
+    if (gcn::group8_enabled() && a.k <= 32 && p->group.nchunks % 64 == 0) snprintf(buf, (size_t)buflen, "gcn::spmm_group8_weighted_kernel<%d>", p->group.T);
+    else snprintf(buf, (size_t)buflen, "gcn::spmm_group_weighted_kernel<%d, %d>", p->group.T, gcn::group_store());
     return GCN_OK;
   }
   gcn::describe_main_kernel(a, buf, (size_t)buflen);

@@ -248,18 +248,18 @@ spmm_group_weighted_kernel(const unsigned short* __restrict__ stream, const floa
 // 8-byte words: u16 4f.. and 32+4f..), same chunk_meta / partial slab / fix list; a wave owns eight consecutive
 // chunks.  The DPP broadcasts still work on rows of 16 lanes = two groups: the upper group of a row takes its
 // entry from a copy rotated by eight lanes.  Two 8-entry blocks are in flight together (sixteen gathers).
-// Value-free only, non-temporal stores.
+// Non-temporal stores; value-free (with the LDS ring) or weighted.
 template <int UU>
 __device__ __forceinline__ int row_ror8_bcast(int v, int vrot, bool upper) {   // entry UU of THIS lane's 8-lane group
   const int lo = row_bcast<UU>(v), hi = row_bcast<UU>(vrot);
   return upper ? hi : lo;
 }
 
-template <int T, bool RING>
-__global__ void __launch_bounds__(256)
-spmm_group8_kernel(const unsigned short* __restrict__ stream, const int2* __restrict__ chunk_meta,
-                   const float* __restrict__ Bp, float* __restrict__ Cv, float* __restrict__ P,
-                   int nchunks, int k, int ldb, int stream_nt) {
+template <int T, bool RING, bool VALS>
+__device__ __forceinline__ void
+group8_walk(const unsigned short* __restrict__ stream, const float* __restrict__ vals, const int2* __restrict__ chunk_meta,
+            const float* __restrict__ Bp, float* __restrict__ Cv, float* __restrict__ P,
+            int nchunks, int k, int ldb, int stream_nt) {
   static_assert(T % 64 == 0, "a chunk is whole runs of 64 entries");
   const int lane = threadIdx.x & 63;
   const int wib  = threadIdx.x >> 6;
@@ -308,6 +308,14 @@ spmm_group8_kernel(const unsigned short* __restrict__ stream, const int2* __rest
   u32x2_g8 w0 = stream_nt ? __builtin_nontemporal_load(sp + f) : sp[f];
   u32x2_g8 w1 = stream_nt ? __builtin_nontemporal_load(sp + 8 + f) : sp[8 + f];
   u32x2_g8 w0_nx = w0, w1_nx = w1;
+  // VALS: the values of the same entries (slicing.hip lays them out like the stream): two 16-byte words per run
+  const f32x4* __restrict__ vp = VALS ? reinterpret_cast<const f32x4*>(vals + (size_t)c * T) : nullptr;
+  f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
+  if constexpr (VALS) {
+    v0 = stream_nt ? __builtin_nontemporal_load(vp + f) : vp[f];
+    v1 = stream_nt ? __builtin_nontemporal_load(vp + 8 + f) : vp[8 + f];
+  }
+  f32x4 v0_nx = v0, v1_nx = v1;
   unsigned fl1 = 0;
 #pragma unroll 1
   for (int d = 0; d < T / 16; ++d) {                            // two 8-entry blocks (2d, 2d+1 of the chunk) per turn
@@ -316,10 +324,22 @@ spmm_group8_kernel(const unsigned short* __restrict__ stream, const int2* __rest
       const u32x2_g8* nx = sp + (d / 4 + 1) * 16;
       w0_nx = stream_nt ? __builtin_nontemporal_load(nx + f) : nx[f];
       w1_nx = stream_nt ? __builtin_nontemporal_load(nx + 8 + f) : nx[8 + f];
+      if constexpr (VALS) {
+        const f32x4* vnx = vp + (d / 4 + 1) * 16;
+        v0_nx = stream_nt ? __builtin_nontemporal_load(vnx + f) : vnx[f];
+        v1_nx = stream_nt ? __builtin_nontemporal_load(vnx + 8 + f) : vnx[8 + f];
+      }
     }
     const unsigned e0 = ((j & 2 ? w0.y : w0.x) >> (16 * (j & 1))) & 0xFFFFu;
     const unsigned e1 = ((j & 2 ? w1.y : w1.x) >> (16 * (j & 1))) & 0xFFFFu;
-    if (j == 3) { w0 = w0_nx; w1 = w1_nx; }
+    int vb0 = 0, vb1 = 0, vb0r = 0, vb1r = 0;                   // this lane's entries' values (bit patterns) and their rotated copies
+    if constexpr (VALS) {
+      vb0 = __builtin_bit_cast(int, j == 0 ? v0.x : j == 1 ? v0.y : j == 2 ? v0.z : v0.w);
+      vb1 = __builtin_bit_cast(int, j == 0 ? v1.x : j == 1 ? v1.y : j == 2 ? v1.z : v1.w);
+      vb0r = __builtin_amdgcn_mov_dpp(vb0, 0x128, 0xf, 0xf, true);
+      vb1r = __builtin_amdgcn_mov_dpp(vb1, 0x128, 0xf, 0xf, true);
+    }
+    if (j == 3) { w0 = w0_nx; w1 = w1_nx; v0 = v0_nx; v1 = v1_nx; }
     const int ro0 = (int)(__umul24((e0 & 0x7FFFu) + (unsigned)base, row_bytes));
     const int ro1 = (int)(__umul24((e1 & 0x7FFFu) + (unsigned)base, row_bytes));
     const int ro0r = __builtin_amdgcn_mov_dpp(ro0, 0x128, 0xf, 0xf, true);   // row_ror:8 — lane l <- lane (l + 8) % 16 of its row
@@ -340,13 +360,20 @@ spmm_group8_kernel(const unsigned short* __restrict__ stream, const int2* __rest
 #undef GCN_G8_GATHER1
     const unsigned long long ends0 = __ballot(fl0 != 0);        // bit g*8+u: entry u of group g (first block) ends a row
     const unsigned long long ends1 = __ballot(fl1 != 0);
-#define GCN_G8_ADD(I) acc.x += b[I].x; acc.y += b[I].y; acc.z += b[I].z; acc.w += b[I].w;
+#define GCN_G8_ADDV(UU, I, VB, VBR)                                                                 \
+      if constexpr (VALS) {                                                                         \
+        const float vu = __builtin_bit_cast(float, row_ror8_bcast<UU>(VB, VBR, upper));             \
+        acc.x = fmaf(vu, b[I].x, acc.x); acc.y = fmaf(vu, b[I].y, acc.y);                           \
+        acc.z = fmaf(vu, b[I].z, acc.z); acc.w = fmaf(vu, b[I].w, acc.w);                           \
+      } else { acc.x += b[I].x; acc.y += b[I].y; acc.z += b[I].z; acc.w += b[I].w; }
+#define GCN_G8_ADD0(UU) GCN_G8_ADDV(UU, UU, vb0, vb0r)
+#define GCN_G8_ADD1(UU) GCN_G8_ADDV(UU, 8 + UU, vb1, vb1r)
     if ((ends0 | ends1) == 0ull) {
-      GCN_G8_ADD(0) GCN_G8_ADD(1) GCN_G8_ADD(2) GCN_G8_ADD(3) GCN_G8_ADD(4) GCN_G8_ADD(5) GCN_G8_ADD(6) GCN_G8_ADD(7)
-      GCN_G8_ADD(8) GCN_G8_ADD(9) GCN_G8_ADD(10) GCN_G8_ADD(11) GCN_G8_ADD(12) GCN_G8_ADD(13) GCN_G8_ADD(14) GCN_G8_ADD(15)
+      GCN_G8_ALL(GCN_G8_ADD0)
+      GCN_G8_ALL(GCN_G8_ADD1)
     } else {
-#define GCN_G8_STEP(UU, I, ENDS, FL, FLR)                                                           \
-      GCN_G8_ADD(I)                                                                                 \
+#define GCN_G8_STEP(UU, I, ENDS, FL, FLR, VB, VBR)                                                  \
+      GCN_G8_ADDV(UU, I, VB, VBR)                                                                   \
       if (ENDS & (0x0101010101010101ull << UU)) {                /* some group ends a row here */    \
         if (row_ror8_bcast<UU>((int)FL, FLR, upper)) {                                              \
           if (RING && !(first && head) && ring_n < 8) {                                             \
@@ -358,8 +385,8 @@ spmm_group8_kernel(const unsigned short* __restrict__ stream, const int2* __rest
           ptr = nptr; nptr += kk; first = false;                                                    \
         }                                                                                           \
       }
-#define GCN_G8_STEP0(UU) GCN_G8_STEP(UU, UU, ends0, fl0, fl0r)
-#define GCN_G8_STEP1(UU) GCN_G8_STEP(UU, 8 + UU, ends1, fl1, fl1r)
+#define GCN_G8_STEP0(UU) GCN_G8_STEP(UU, UU, ends0, fl0, fl0r, vb0, vb0r)
+#define GCN_G8_STEP1(UU) GCN_G8_STEP(UU, 8 + UU, ends1, fl1, fl1r, vb1, vb1r)
       GCN_G8_ALL(GCN_G8_STEP0)
       GCN_G8_ALL(GCN_G8_STEP1)
 #undef GCN_G8_STEP0
@@ -379,7 +406,9 @@ spmm_group8_kernel(const unsigned short* __restrict__ stream, const int2* __rest
         }
       }
     }
-#undef GCN_G8_ADD
+#undef GCN_G8_ADD1
+#undef GCN_G8_ADD0
+#undef GCN_G8_ADDV
 #undef GCN_G8_ALL
   }
   if constexpr (RING) {                                         // what is left in the rings
@@ -407,9 +436,26 @@ bool spmm_group_eligible(int k, int ldb, const void* B, const void* C, const voi
   return k % 4 == 0 && ldb % 4 == 0 && (al & 15) == 0 && ldb * 4 < (1 << 24);
 }
 
-// k <= 32, value-free, whole waves of eight chunks per XCD: the eight-engine kernel takes the launch
+template <int T, bool RING>
+__global__ void __launch_bounds__(256)
+spmm_group8_kernel(const unsigned short* __restrict__ stream, const int2* __restrict__ chunk_meta,
+                   const float* __restrict__ Bp, float* __restrict__ Cv, float* __restrict__ P,
+                   int nchunks, int k, int ldb, int stream_nt) {
+  group8_walk<T, RING, false>(stream, nullptr, chunk_meta, Bp, Cv, P, nchunks, k, ldb, stream_nt);
+}
+
+// ... and with the values beside the stream (matrices whose values do not factor); no ring: 138 VGPRs without
+template <int T>
+__global__ void __launch_bounds__(256)
+spmm_group8_weighted_kernel(const unsigned short* __restrict__ stream, const float* __restrict__ vals,
+                            const int2* __restrict__ chunk_meta, const float* __restrict__ Bp, float* __restrict__ Cv,
+                            float* __restrict__ P, int nchunks, int k, int ldb, int stream_nt) {
+  group8_walk<T, false, true>(stream, vals, chunk_meta, Bp, Cv, P, nchunks, k, ldb, stream_nt);
+}
+
+// k <= 32, whole waves of eight chunks per XCD: the eight-engine kernels take the launch
 bool spmm_group8_applies(const GroupArgs& a) {
-  return a.narrow8 && !a.vals && a.k <= 32 && a.k % 4 == 0 && a.nchunks % 64 == 0;
+  return a.narrow8 && a.k <= 32 && a.k % 4 == 0 && a.nchunks % 64 == 0;
 }
 
 hipError_t launch_spmm_group(const GroupArgs& a, hipStream_t s) {
@@ -420,20 +466,24 @@ hipError_t launch_spmm_group(const GroupArgs& a, hipStream_t s) {
   const int tiles = (a.k + 63) / 64;
   const int ldb = a.ldb > 0 ? a.ldb : a.k;
   if (spmm_group8_applies(a)) {                        // k <= 32: eight 8-lane row engines per wave
-    const int stream_nt8 = (size_t)a.nchunks * (size_t)a.T * 2u > ((size_t)64 << 20) ? 1 : 0;
+    const int stream_nt8 = (size_t)a.nchunks * (size_t)a.T * (a.vals ? 6u : 2u) > ((size_t)64 << 20) ? 1 : 0;
     const int nb8 = 8 * ((per_xcd + 31) / 32);
     const int2* meta = reinterpret_cast<const int2*>(a.chunk_meta);
     switch (a.T) {
-      case 256:  if (a.ring) spmm_group8_kernel<256, true><<<dim3(nb8), dim3(256), 0, s>>>(a.stream, meta, a.Bp, a.Cv, a.P, a.nchunks, a.k, ldb, stream_nt8);
+      case 256:  if (a.vals)      spmm_group8_weighted_kernel<256><<<dim3(nb8), dim3(256), 0, s>>>(a.stream, a.vals, meta, a.Bp, a.Cv, a.P, a.nchunks, a.k, ldb, stream_nt8);
+                 else if (a.ring) spmm_group8_kernel<256, true><<<dim3(nb8), dim3(256), 0, s>>>(a.stream, meta, a.Bp, a.Cv, a.P, a.nchunks, a.k, ldb, stream_nt8);
                  else        spmm_group8_kernel<256, false><<<dim3(nb8), dim3(256), 0, s>>>(a.stream, meta, a.Bp, a.Cv, a.P, a.nchunks, a.k, ldb, stream_nt8);
                  break;
-      case 512:  if (a.ring) spmm_group8_kernel<512, true><<<dim3(nb8), dim3(256), 0, s>>>(a.stream, meta, a.Bp, a.Cv, a.P, a.nchunks, a.k, ldb, stream_nt8);
+      case 512:  if (a.vals)      spmm_group8_weighted_kernel<512><<<dim3(nb8), dim3(256), 0, s>>>(a.stream, a.vals, meta, a.Bp, a.Cv, a.P, a.nchunks, a.k, ldb, stream_nt8);
+                 else if (a.ring) spmm_group8_kernel<512, true><<<dim3(nb8), dim3(256), 0, s>>>(a.stream, meta, a.Bp, a.Cv, a.P, a.nchunks, a.k, ldb, stream_nt8);
                  else        spmm_group8_kernel<512, false><<<dim3(nb8), dim3(256), 0, s>>>(a.stream, meta, a.Bp, a.Cv, a.P, a.nchunks, a.k, ldb, stream_nt8);
                  break;
-      case 1024: if (a.ring) spmm_group8_kernel<1024, true><<<dim3(nb8), dim3(256), 0, s>>>(a.stream, meta, a.Bp, a.Cv, a.P, a.nchunks, a.k, ldb, stream_nt8);
+      case 1024: if (a.vals)      spmm_group8_weighted_kernel<1024><<<dim3(nb8), dim3(256), 0, s>>>(a.stream, a.vals, meta, a.Bp, a.Cv, a.P, a.nchunks, a.k, ldb, stream_nt8);
+                 else if (a.ring) spmm_group8_kernel<1024, true><<<dim3(nb8), dim3(256), 0, s>>>(a.stream, meta, a.Bp, a.Cv, a.P, a.nchunks, a.k, ldb, stream_nt8);
                  else        spmm_group8_kernel<1024, false><<<dim3(nb8), dim3(256), 0, s>>>(a.stream, meta, a.Bp, a.Cv, a.P, a.nchunks, a.k, ldb, stream_nt8);
                  break;
-      case 2048: if (a.ring) spmm_group8_kernel<2048, true><<<dim3(nb8), dim3(256), 0, s>>>(a.stream, meta, a.Bp, a.Cv, a.P, a.nchunks, a.k, ldb, stream_nt8);
+      case 2048: if (a.vals)      spmm_group8_weighted_kernel<2048><<<dim3(nb8), dim3(256), 0, s>>>(a.stream, a.vals, meta, a.Bp, a.Cv, a.P, a.nchunks, a.k, ldb, stream_nt8);
+                 else if (a.ring) spmm_group8_kernel<2048, true><<<dim3(nb8), dim3(256), 0, s>>>(a.stream, meta, a.Bp, a.Cv, a.P, a.nchunks, a.k, ldb, stream_nt8);
                  else        spmm_group8_kernel<2048, false><<<dim3(nb8), dim3(256), 0, s>>>(a.stream, meta, a.Bp, a.Cv, a.P, a.nchunks, a.k, ldb, stream_nt8);
                  break;
       default: return hipErrorInvalidValue;
