@@ -664,7 +664,8 @@ def test_value_free_sliced_pass_for_normalised_adjacencies():
     val3 = (rng.random(len(val)) + 0.1).astype(np.float32)
     adj3 = _adj(rowptr, col, val3, n, n)
     assert adj3.main_kernel(128).startswith("gcn::spmm_group_weighted_kernel<")
-    for k in (64, 100, 41):                              # 100, 41: on the row-padded / odd-width copies
+    assert adj3.main_kernel(16).startswith("gcn::spmm_group8_weighted_kernel<")   # k <= 32: eight engines per wave
+    for k in (64, 100, 41, 16, 20, 30):                  # 100, 41, 30: on the row-padded / odd-width copies
         Bk = rng.standard_normal((n, k)).astype(np.float32)
         assert rel_err(adj3.matmul_raw(torch.from_numpy(Bk).to(_dev())).cpu().numpy(), oracle_spmm(rowptr, col, val3, Bk)) <= TOL
     assert rel_err(adj3.matmul_raw(torch.from_numpy(B).to(_dev())).cpu().numpy(), oracle_spmm(rowptr, col, val3, B)) <= TOL
