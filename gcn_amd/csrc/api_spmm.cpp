@@ -169,6 +169,12 @@ int auto_slices(long long m, long long n, long long nnz, bool value_free) {
   return S;
 }
 
+// the drop-in csr2tile / flexspmm pair packs and runs the group-kernel format (api_dropin.cpp)
+bool dropin_group_format_enabled() {
+  static const bool v = env_on("GCN_AMD_DROPIN_GROUP");
+  return v && group_enabled();
+}
+
 void die(const char* what, hipError_t e) {
   std::fprintf(stderr, "libgcnspmm: %s failed: %s\n", what, hipGetErrorString(e));
   std::abort();

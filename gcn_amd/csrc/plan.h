@@ -169,6 +169,7 @@ int auto_tile_cols(long long n, int k);
 int auto_slices(long long m, long long n, long long nnz, bool value_free = false);
 int padded_ldb(long long n, int k);
 bool pad_b_enabled();
+bool dropin_group_format_enabled();
 [[noreturn]] void die(const char* what, hipError_t e);
 bool verbose();
 // scratch plan of the stateless entry points (oneshot / cuspmm / flexspmm): one per (device, stream), never freed

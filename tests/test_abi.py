@@ -108,9 +108,36 @@ def test_csr2tile_packing_respects_caller_capacities():
     assert np.array_equal(segNzCV[nnz:2 * nnz].numpy(), val)
 
 
-def test_csr2tile_slice_major_packing_is_a_permutation_of_the_matrix():
-    """host-only: for a dense graph csr2tile packs S*m virtual rows (row r's entries split by
-    column slice, slice-major); unpacking them gives back exactly the input matrix"""
+def _unpack_group_format(seg_rowPtr, segNzCV, segVoMap, n):
+    """decode what csr2tile packs for graphs that qualify for slicing (api_dropin.cpp: the group-kernel format)
+    → (header dict, rows, cols, vals or None, u or None, logical stream)"""
+    h = seg_rowPtr.numpy()[:16]
+    hd = dict(magic=int(h[0]), S=int(h[1]), T=int(h[2]), w=int(h[3]), nchunks=int(h[4]), nfix=int(h[5]),
+              value_free=int(h[6]), total=int(h[7]), nnz=int(h[8]))
+    total, S, w = hd["total"], hd["S"], hd["w"]
+    p = np.arange(total, dtype=np.int64)
+    r = p & 63
+    phys = (p & ~np.int64(63)) + (r & 15) * 4 + (r >> 4)              # lane-major runs of 64 entries
+    stream = segNzCV.numpy().view(np.uint16)[:total][phys]
+    ends, off = (stream >> 15).astype(np.int64), (stream & 0x7FFF).astype(np.int64)
+    vrow = np.concatenate([[0], np.cumsum(ends)[:-1]])
+    assert int(ends.sum()) == S * n                                    # every virtual row ends exactly once
+    real = off < w                                                     # (off == w: padding entry, the all-zero row)
+    rows, cols = (vrow % n)[real], ((vrow // n) * w + off)[real]
+    vals = u = None
+    if hd["value_free"]:
+        u = segVoMap.numpy()[:n].view(np.float32)
+    else:
+        voff = (total * 2 + 15) // 16 * 4
+        vals = segNzCV.numpy()[voff: voff + total][phys][real]
+        assert np.all(segNzCV.numpy()[voff: voff + total][phys][~real] == 0)      # padding weighs nothing
+    return hd, rows, cols, vals, u, (vrow, ends, real)
+
+
+def test_csr2tile_group_format_is_the_matrix():
+    """host-only: for a graph that qualifies for slicing csr2tile packs the group kernels' format — slice-major 15-bit
+    stream in lane-major runs, chunk metadata, list of cut rows; value-free when the values are u[r]*u[c], with the
+    values beside the stream otherwise.  Unpacking gives back exactly the input matrix."""
     import scipy.sparse as sp
     import torch
     from gcn_amd import dropin
@@ -119,27 +146,44 @@ def test_csr2tile_slice_major_packing_is_a_permutation_of_the_matrix():
     rowptr, col, val = sym_norm_graph(n, 1200000, seed=2)
     nnz = len(col)
     assert nnz // n >= 128
+    A = sp.csr_matrix((val, col, rowptr), shape=(n, n))
     rng = np.random.default_rng(0)           # hand the rows over UNSORTED: csr2tile sorts them itself
     col_u, val_u = col.copy(), val.copy()
     for r in range(n):
         p = rng.permutation(rowptr[r + 1] - rowptr[r]) + rowptr[r]
         col_u[rowptr[r]:rowptr[r + 1]], val_u[rowptr[r]:rowptr[r + 1]] = col[p], val[p]
-    seg_rowPtr, segNzCV, segVoMap, tail, nxt, n_segs = dropin.csr2tile(
-        torch.from_numpy(rowptr.copy()), torch.from_numpy(col_u), torch.from_numpy(val_u), n, n, nnz,
-        torch.arange(n, dtype=torch.int32))
-    S, w = 2, (n + 1) // 2
-    vrp = seg_rowPtr.numpy()[: S * n + 1]
-    assert vrp[0] == 0 and vrp[-1] == nnz and np.all(np.diff(vrp) >= 0)
-    vcol = segNzCV[:nnz].numpy().view(np.int32)
-    vval = segNzCV[nnz:2 * nnz].numpy()
-    rows = np.repeat(np.arange(S * n), np.diff(vrp))
-    assert np.array_equal(vcol // w, rows // n)                       # every entry sits in its slice
-    A = sp.csr_matrix((val, col, rowptr), shape=(n, n))
-    Bm = sp.coo_matrix((vval, (rows % n, vcol)), shape=(n, n)).tocsr()
-    Bm.sort_indices()
-    assert np.array_equal(Bm.indptr, A.indptr) and np.array_equal(Bm.indices, A.indices)
-    assert np.array_equal(Bm.data, A.data)
-    # chunk_row of the virtual CSR: monotone over the used prefix, within range
-    cr = segVoMap.numpy()
-    lead = np.trim_zeros(cr, "b")
-    assert len(lead) >= 1 and np.all(np.diff(lead) >= 0) and cr.max() < S * n
+    for weighted in (False, True):
+        vin = val_u.copy()
+        if weighted:
+            vin[5] *= 1.5                    # no longer u[r]*u[c]: the values travel beside the stream
+        seg_rowPtr, segNzCV, segVoMap, tail, nxt, n_segs = dropin.csr2tile(
+            torch.from_numpy(rowptr.copy()), torch.from_numpy(col_u.copy()), torch.from_numpy(vin), n, n, nnz,
+            torch.arange(n, dtype=torch.int32))
+        hd, rows, cols, vals, u, (vrow, ends, real) = _unpack_group_format(seg_rowPtr, segNzCV, segVoMap, n)
+        assert hd["magic"] == 0x47434E47 and hd["S"] == 2 and hd["T"] == 512 and hd["w"] == (n + 1) // 2
+        assert hd["nnz"] == nnz and hd["total"] == hd["nchunks"] * 512 and hd["nchunks"] % 64 == 0
+        assert hd["value_free"] == (0 if weighted else 1)
+        Bm = sp.coo_matrix((np.ones(len(rows)), (rows, cols)), shape=(n, n)).tocsr()
+        Bm.sort_indices()
+        assert np.array_equal(Bm.indptr, A.indptr) and np.array_equal(Bm.indices, A.indices)   # the same pattern
+        if weighted:
+            got = sp.coo_matrix((vals, (rows, cols)), shape=(n, n)).tocsr(); got.sort_indices()
+            ref = sp.csr_matrix((vin, col_u, rowptr), shape=(n, n)); ref.sort_indices()
+            assert np.array_equal(got.data, ref.data)                                          # the values, exactly
+        else:
+            assert np.allclose(u[rows] * u[cols], np.asarray(A[rows, cols]).ravel(), rtol=1e-6, atol=0)
+        # chunk metadata: chunk c starts inside virtual row vrow[c*T]; flag = the row began in an earlier chunk
+        meta = seg_rowPtr.numpy()[16: 16 + 2 * hd["nchunks"]].reshape(-1, 2)
+        starts = np.arange(hd["nchunks"], dtype=np.int64) * 512
+        assert np.array_equal(meta[:, 0] >> 1, vrow[starts])
+        began = np.concatenate([[0], (ends[starts[1:] - 1] == 0).astype(np.int64)])
+        assert np.array_equal(meta[:, 0] & 1, began)
+        assert np.array_equal(meta[:, 1], (vrow[starts] // n) * (hd["w"] + 1))
+        # fix list: exactly the rows that begin in chunk c-1 and run on into chunk c
+        foff = (16 + 2 * hd["nchunks"] + 3) // 4 * 4
+        fix = seg_rowPtr.numpy()[foff: foff + 4 * hd["nfix"]].reshape(-1, 4)
+        cut = np.flatnonzero(began[1:] == 1) + 1
+        first_of_row = np.concatenate([[0], np.flatnonzero(ends[:-1] == 1) + 1])              # start entry of every vrow
+        cut = cut[first_of_row[vrow[starts[cut]]] // 512 == cut - 1]
+        assert hd["nfix"] == len(cut) and np.array_equal(np.sort(fix[:, 1]), cut)
+        assert np.array_equal(fix[np.argsort(fix[:, 1]), 0], vrow[starts[cut]])

@@ -433,27 +433,35 @@ def test_slicing_refuses_unsorted_rows():
     assert rel_err(adj.matmul_raw(torch.from_numpy(B).to(_dev())).cpu().numpy(), oracle_spmm(rowptr, col, val, B)) <= TOL
 
 
-def test_dropin_pair_with_xcd_slicing_on_a_dense_graph():
-    """mean degree >= 128: csr2tile packs the slice-major virtual CSR and flexspmm (which only
-    sees device pointers, m, n, k, n_segs) recovers S, the chunk size and nnz by itself"""
+def test_dropin_pair_on_a_dense_graph_runs_the_group_kernels():
+    """mean degree >= 128 and a feature table larger than an L2: csr2tile packs the group kernels' format (stream,
+    chunk metadata, cut rows; value-free for a normalised adjacency, weighted otherwise) into the caller's buffers and
+    flexspmm — which only sees device pointers, m, n, k, n_segs — runs the plan API's kernels on it, at every width"""
     n = 17000                                # 64-column table 4.35 MB > one 4 MiB L2 -> 2 slices (auto_slices)
     rowptr, col, val = sym_norm_graph(n, 1200000, seed=12)
     nnz = len(col)
     assert nnz // n >= 128
     d = _dev()
-    t_rp, t_ci, t_va = torch.from_numpy(rowptr.copy()), torch.from_numpy(col.copy()), torch.from_numpy(val.copy())
-    out = dropin.csr2tile(t_rp, t_ci, t_va, n, n, nnz, torch.arange(n, dtype=torch.int32))
-    seg_rowPtr, segNzCV, segVoMap, tail, nxt, n_segs = out
-    # the packed row pointer is the virtual one: S*m rows, ends at nnz
-    S = 2
-    assert int(seg_rowPtr[S * n]) == nnz and int(seg_rowPtr[n]) < nnz
-    dev = [t.to(d) for t in (seg_rowPtr, segNzCV, segVoMap, tail, nxt)]
     rng = np.random.default_rng(5)
-    for k in (16, 41, 128, 200):
-        X = rng.standard_normal((n, k)).astype(np.float32)
-        Xd = torch.from_numpy(X).to(d)
-        C = dropin.flexspmm.apply(dev[0], dev[1], dev[2], n, n, int(n_segs[0]), dev[3], dev[4], Xd)
-        assert rel_err(C.cpu().numpy(), oracle_spmm(rowptr, col, val, X)) <= TOL
+    for weighted in (False, True):
+        v = val.copy()
+        if weighted:
+            v = (v * (1.0 + 0.5 * rng.random(nnz))).astype(np.float32)
+        t_rp, t_ci, t_va = torch.from_numpy(rowptr.copy()), torch.from_numpy(col.copy()), torch.from_numpy(v.copy())
+        out = dropin.csr2tile(t_rp, t_ci, t_va, n, n, nnz, torch.arange(n, dtype=torch.int32))
+        seg_rowPtr, segNzCV, segVoMap, tail, nxt, n_segs = out
+        hdr = seg_rowPtr.numpy()[:9]
+        assert hdr[0] == 0x47434E47 and hdr[1] == 2 and hdr[6] == (0 if weighted else 1) and hdr[8] == nnz
+        dev = [t.to(d) for t in (seg_rowPtr, segNzCV, segVoMap, tail, nxt)]
+        for k in (1, 3, 7, 16, 32, 41, 100, 128, 200):
+            X = rng.standard_normal((n, k)).astype(np.float32)
+            Xd = torch.from_numpy(X).to(d).requires_grad_(True)
+            C = dropin.flexspmm.apply(dev[0], dev[1], dev[2], n, n, int(n_segs[0]), dev[3], dev[4], Xd)
+            assert rel_err(C.detach().cpu().numpy(), oracle_spmm(rowptr, col, v, X)) <= TOL, (weighted, k)
+            if k == 128 and not weighted:                                   # backward = the same op (Â symmetric)
+                G = rng.standard_normal((n, k)).astype(np.float32)
+                C.backward(torch.from_numpy(G).to(d))
+                assert rel_err(Xd.grad.cpu().numpy(), oracle_spmm(rowptr, col, v, G)) <= TOL
 
 
 def test_full_size_products_shape_rcm_reordered():
