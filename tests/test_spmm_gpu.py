@@ -464,6 +464,28 @@ def test_dropin_pair_on_a_dense_graph_runs_the_group_kernels():
                 assert rel_err(Xd.grad.cpu().numpy(), oracle_spmm(rowptr, col, v, G)) <= TOL
 
 
+def test_dropin_flexspmm_refuses_buffers_it_did_not_pack():
+    """for a graph shape that takes the group-kernel format flexspmm reads csr2tile's header back; buffers without it
+    (here: zeros) are refused with a message and abort(), never computed on — checked in a child process"""
+    import subprocess
+    import sys
+    code = (
+        "import torch, ctypes, gcn_amd\n"
+        "n, nnz = 17000, 2400000\n"
+        "d = torch.device('cuda:0')\n"
+        "vp = lambda t: ctypes.c_void_p(t.data_ptr())\n"
+        "z = lambda k, dt: torch.zeros(k, dtype=dt, device=d)\n"
+        "a, b, c = z(9 * (nnz // 9), torch.int32), z(2 * nnz, torch.float32), z(8 * (nnz // 9), torch.int32)\n"
+        "t, x = z(256, torch.int32), z(256, torch.int32)\n"
+        "B, C = torch.ones((n, 64), device=d), torch.empty((n, 64), device=d)\n"
+        "gcn_amd.load_library().flexspmm(vp(a), vp(b), vp(c), vp(t), vp(x), n, n, 64, nnz // 9, vp(B), vp(C))\n"
+        "torch.cuda.synchronize(); print('computed')\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode != 0 and "computed" not in r.stdout
+    assert "not packed by this library's csr2tile" in r.stderr
+
+
 def test_full_size_products_shape_rcm_reordered():
     """BASELINE config 3: products-shaped graph (n = 2 449 029, nnz ≈ 126.2 M), k = 256,
     RCM-reordered by the build's order_rcm.  Checked through size-independent properties:
