@@ -260,7 +260,9 @@ void csr2tile(int* rowPtr, int* colIdx, float* vals, int m, int n, int nnz,
               int* grouped_tailSeg, int* next_seg, int tm, int* n_segs);
 
 /* flexspmm.so — flexspmm.cu:499-502.  All pointers DEVICE.  Consumes the arrays
- * written by this library's csr2tile.  Legacy default stream. */
+ * written by this library's csr2tile (plain CSR, or — square graphs that qualify for XCD-aware slicing — the group
+ * kernels' stream format).  Legacy default stream; in the group format one 64-byte header is
+ * copied back synchronously per call, and buffers without it are refused (message + abort). */
 void flexspmm(int* seg_rowPtr, float* segNzCV, int* segVoMap,
               int* grouped_tailSeg, int* next_seg,
               int m, int n, int k, int n_segs, float* B, float* C);
