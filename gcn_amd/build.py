@@ -17,6 +17,7 @@ LIBDIR = os.path.join(HERE, "lib")
 DROPIN = os.path.join(HERE, "dropin")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(LIBDIR, "libgcnspmm.so")
+OBJDIR = os.path.join(LIBDIR, "obj")
 ARCH = "gfx950"
 DROPIN_NAMES = ["flexspmm.so", "cuspmm.so", "tile.so", "permutate.so", "renumber.so"]
 
@@ -38,15 +39,37 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _compile_one(args):
+    src, obj, verbose = args
+    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++20", "-fPIC", "-fvisibility=default", "-Wall",
+           "-Wno-unused-result", "-x", "hip", "-c", src, "-o", obj]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return obj
+
+
 def build(force=False, verbose=False):
+    """One object per translation unit (no relocatable device code: the units share headers only), compiled in
+    parallel and re-compiled only when the unit or a header changed; then one link."""
+    from concurrent.futures import ThreadPoolExecutor
     os.makedirs(LIBDIR, exist_ok=True)
+    os.makedirs(OBJDIR, exist_ok=True)
     os.makedirs(DROPIN, exist_ok=True)
-    srcs = [os.path.join(CSRC, s) for s in SOURCES]
     hdrs = [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
-    if force or _stale(LIB, srcs + hdrs + [os.path.abspath(__file__)]):
-        cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++20", "-fPIC", "-shared",
-               "-fvisibility=default", "-Wall", "-Wno-unused-result",
-               "-x", "hip", *srcs, "-o", LIB]
+    me = os.path.abspath(__file__)
+    jobs, objs = [], []
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(OBJDIR, os.path.splitext(s)[0] + ".o")
+        objs.append(obj)
+        if force or _stale(obj, [src, me] + hdrs):
+            jobs.append((src, obj, verbose))
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(len(jobs), max(1, (os.cpu_count() or 2) - 1))) as ex:
+            list(ex.map(_compile_one, jobs))
+    if force or jobs or _stale(LIB, objs):
+        cmd = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", LIB]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
