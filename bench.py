@@ -15,9 +15,18 @@ timed region starts.  After the timed loop the output of the last step is checke
 an fp64 evaluation (torch arithmetic, gcn_amd/check.py); the run fails above 1e-5.  Prints ONE JSON line on
 rank 0.
 
-`--graph papers100m` (BASELINE config 4; not the headline metric): n = 111 059 956, 1.616 G directed R-MAT
-samples, ≈ 3.3 G non-zeros in the whole graph, generated block by block; N = 8 ranks hold one block each,
-and on ONE GPU the run is rank 0's share of the 8-way partition (compute only), stated as such.
+The other BASELINE configs run through the same code and print the same line (not the headline metric; the
+driver only runs the default):
+`--graph products` (config 3): products-shaped graph, feat = 256, renumbered by the library's device RCM
+  (the same integers as the host order_rcm) before the SpMM; `--order none|deg|rcm|gorder` overrides.
+`--graph rmat24` (config 5): Graph500 R-MAT scale 24 (`--rmat-scale` for smaller ones), feat = 512,
+  `--order none|deg|rcm|gorder` (Gorder is the host algorithm, window 3; its host seconds are printed).
+`--graph papers100m` (config 4): n = 111 059 956, 1.616 G directed R-MAT samples, ≈ 3.3 G non-zeros in the
+  whole graph, generated block by block; N = 8 ranks hold one block each, and on ONE GPU the run is rank 0's
+  share of the 8-way partition (compute only), stated as such.
+For graphs whose feature table is far larger than the caches (configs 3-5) `roofline.bound` is "hbm" and
+`roofline.frac` is the SURVEY §8(d) figure itself (algorithmic bytes / kernel time / 8 TB/s); for the column-
+sliced Reddit-shaped run the gathers are served by L2 and `bound` says "l2".
 """
 import argparse
 import json
@@ -45,8 +54,10 @@ from gcn_amd.dist import PipelinedAggregation, RowShardedAdjacency   # noqa: E40
 HBM_PEAK = 8.0e12
 L2_PEAK = 34.5e12
 FABRIC_GATHER_CEILING = 8.6e12
-K_FEAT = 128
+K_FEAT = {"reddit": 128, "products": 256, "rmat24": 512, "papers100m": 128}     # BASELINE.json configs 2-5
+ORDER = {"reddit": "none", "products": "rcm", "rmat24": "none", "papers100m": "none"}
 TOL = 1e-5
+CPU_SAMPLE_WORK = 1.6e10          # nnz x k of the CPU-baseline sample: about 10 s per torch.spmm on the box's host
 PAPERS_N, PAPERS_SAMPLES = 111059956, 1615685872
 
 
@@ -55,29 +66,38 @@ def algorithmic_bytes(m, nnz, k):
     return nnz * (4 + 4 + 4 * k) + (m + 1) * 4 + m * k * 4
 
 
-def pmc_traffic(graph, k, passes, kernel):
-    """Fabric-side bytes per main-kernel launch from the committed PMC summary (separate `rocprofv3 --pmc`
-    passes of this same bench command, tools/pmc_summary.py) — only if that summary was taken for the
-    kernel this run timed; else None (traffic is then 'not collected')."""
+def pmc_traffic(graph, k, order, passes, kernel):
+    """Fabric-side bytes per main-kernel launch from the committed PMC summaries (separate `rocprofv3 --pmc`
+    passes of this same bench command, tools/pmc_summary.py) — only if a summary was taken for this graph,
+    width, ordering and the kernel this run timed; else None (traffic is then 'not collected').
+    → (bytes, l2_hit_rate, file) or None"""
     try:
         d = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
-        if (d.get("graph") == graph and d.get("k") == k and d.get("launches_per_spmm") == passes
-                and any(kernel in name for name in d.get("kernel", []))):
-            return int(d["traffic_bytes_per_launch"])
-    except (OSError, ValueError, KeyError, TypeError):
-        pass
+    except (OSError, ValueError):
+        return None
+    for e in d.get("entries", [d]):
+        try:
+            if (e.get("graph") == graph and e.get("k") == k and e.get("order", "none") == order
+                    and e.get("launches_per_spmm") == passes and any(kernel in name for name in e.get("kernel", []))):
+                return int(e["traffic_bytes_per_launch"]), e.get("l2_hit_rate"), e.get("source", "profiles/pmc_latest.json")
+        except (KeyError, TypeError, ValueError):
+            continue
     return None
 
 
-def cpu_baseline(rowptr, col, val, n, k, seed):
-    """pygcn's CPU path: torch.spmm(adj_sparse_coo_fp32, dense) exactly as gcn1.py:53 issues it,
-    on this box's host cores (baseline only): 1 warm-up + 3 timed repetitions, median."""
+def cpu_baseline(rowptr, col, val, n, k, H, graph):
+    """pygcn's CPU path: torch.spmm(adj_sparse_coo_fp32, dense) exactly as gcn1.py:53 issues it, on this box's
+    host cores (baseline only): 1 warm-up + 3 timed repetitions, median.  Bounded sample: the
+    leading rows of the matrix up to CPU_SAMPLE_WORK = nnz x k (the whole Reddit-shaped graph at k = 128 is just
+    below it), against the full feature matrix."""
     rp = rowptr.cpu().long()
-    rows = torch.repeat_interleave(torch.arange(n, dtype=torch.int64), rp[1:] - rp[:-1])
-    idx = torch.stack([rows, col.cpu().long()])
-    adj = torch.sparse_coo_tensor(idx, val.cpu(), (n, n))      # as utils.py:243-250 builds it
-    B = graphgen.random_features(n, k, seed=seed, device="cpu")
-    nnz = int(val.numel())
+    budget = int(CPU_SAMPLE_WORK / k)
+    rows_s = n if int(rp[-1]) <= budget else max(1, int(torch.searchsorted(rp, torch.tensor(budget))) - 1)
+    nnz_s = int(rp[rows_s])
+    rows = torch.repeat_interleave(torch.arange(rows_s, dtype=torch.int64), rp[1:rows_s + 1] - rp[:rows_s])
+    idx = torch.stack([rows, col[:nnz_s].cpu().long()])
+    adj = torch.sparse_coo_tensor(idx, val[:nnz_s].cpu(), (rows_s, n))      # as utils.py:243-250 builds it
+    B = H.cpu()
     times = []
     torch.spmm(adj, B)                                         # warm-up
     for _ in range(3):
@@ -86,14 +106,38 @@ def cpu_baseline(rowptr, col, val, n, k, seed):
         times.append(time.perf_counter() - t0)
     times.sort()
     med = times[len(times) // 2]
+    whole = rows_s == n
     return {
-        "value": round(2.0 * nnz * k / med / 1e9, 3), "unit": "GFLOP/s",
+        "value": round(2.0 * nnz_s * k / med / 1e9, 3), "unit": "GFLOP/s",
         "cores": torch.get_num_threads(), "kind": "reference",
-        "sample": f"torch.spmm(sparse_coo fp32, dense) as pygcn/gcn1.py:53, full Reddit-shaped graph "
-                  f"(nnz={nnz}, k={k}), median of {len(times)} runs after 1 warm-up, "
+        "sample": f"torch.spmm(sparse_coo fp32, dense) as pygcn/gcn1.py:53, "
+                  + (f"full {graph}-shaped graph" if whole else f"leading {rows_s} of {n} rows of the {graph}-shaped graph")
+                  + f" (nnz={nnz_s}, k={k}), median of {len(times)} runs after 1 warm-up, "
                   f"os.cpu_count()={os.cpu_count()}, torch {torch.__version__}",
         "seconds_per_spmm": round(med, 4),
     }
+
+
+def renumber(rowptr, col, val, order, dev):
+    """the adjacency in the numbering of `order` (device CSR rewrite); → (rowptr, col, val, seconds of the ordering,
+    where it ran).  deg / rcm: the library's device versions (bit-identical to order_deg / order_rcm of the host code);
+    gorder: the host algorithm (window 3, renumber.cu:176), the only form that exists."""
+    from gcn_amd import reorder
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    if order == "deg":
+        rank, where = reorder.order_deg_device(rowptr, col, "total", True), "device"
+    elif order == "rcm":
+        rank, where = reorder.order_rcm_device(rowptr, col), "device"
+    elif order == "gorder":
+        rank = torch.from_numpy(reorder.order_gorder(rowptr.cpu().numpy(), col.cpu().numpy(), 3)).to(dev)
+        where = "host (1 thread)"
+    else:
+        raise ValueError(order)
+    torch.cuda.synchronize()
+    secs = time.perf_counter() - t0
+    rp, ci, va, _vomp = reorder.apply_rank_device(rowptr, col, val, rank)
+    return rp, ci, va, secs, where
 
 
 def main():
@@ -101,8 +145,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--graph", default="reddit", choices=["reddit", "papers100m"])
-    ap.add_argument("--k", type=int, default=K_FEAT)
+    ap.add_argument("--graph", default="reddit", choices=["reddit", "products", "rmat24", "papers100m"])
+    ap.add_argument("--k", type=int, default=0, help="feature width (0 = the width BASELINE.json names for the graph)")
+    ap.add_argument("--order", default="config", choices=["config", "none", "deg", "rcm", "gorder"],
+                    help="single GPU: renumber the graph before the SpMM (config = what BASELINE.json names: RCM for "
+                         "products, none otherwise)")
+    ap.add_argument("--rmat-scale", type=int, default=24, help="--graph rmat24: log2 of the vertex count (24 = config 5)")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the graph (debug only; invalidates the metric)")
     ap.add_argument("--exchange", default="all_gather", choices=["all_gather", "direct"],
                     help="N > 1: one RCCL all-gather per plane and layer, or a grouped send/recv to every peer")
@@ -144,13 +192,17 @@ def main():
         else:
             os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")   # collective kernels ahead of compute in the HW queues
             dist.init_process_group("nccl", device_id=dev)          # nccl == RCCL on ROCm
-    k = args.k
+    k = args.k or K_FEAT[args.graph]
+    order = ORDER[args.graph] if args.order == "config" else args.order
     papers = args.graph == "papers100m"
     sim = args.sim_world if (world == 1 and args.sim_world > 1) else 0
     if papers and world == 1 and not sim:
         sim = 8                                              # one GPU: rank 0's share of the 8-way partition
     sharded = world > 1 or args.force_shard or sim > 1
     part_world, part_rank = (sim, 0) if sim else (world, rank)
+    if sharded and (order != "none" or args.graph in ("products", "rmat24")):
+        sys.exit("bench.py: the row-sharded path runs the reddit / papers100m graphs un-renumbered")
+    order_secs, order_where = 0.0, ""
 
     def make_local(rp, ci, va, shape):
         return gcn_amd.CsrAdjacency(rp, ci, va, shape, chunk_nnz=args.chunk)
@@ -158,7 +210,13 @@ def main():
     # ---- inputs ------------------------------------------------------------------------------
     rowptr = col = val = None
     if not sharded:
-        rowptr, col, val, n = graphgen.make_graph(args.graph, device=dev, seed=1, scale=args.scale)
+        if args.graph == "rmat24":
+            rowptr, col, val, n = graphgen.make_rmat(args.rmat_scale, device=dev, seed=5)
+        else:
+            rowptr, col, val, n = graphgen.make_graph(args.graph, device=dev, seed=1, scale=args.scale)
+        if order != "none":
+            rowptr, col, val, order_secs, order_where = renumber(rowptr, col, val, order, dev)
+            torch.cuda.empty_cache()
         nnz = int(col.numel())
         H = graphgen.random_features(n, k, seed=2, device=dev)
         adj = gcn_amd.CsrAdjacency(rowptr, col, val, (n, n), symmetric=True, chunk_nnz=args.chunk)
@@ -288,12 +346,46 @@ def main():
     achieved = balg / kavg if kavg > 0 else 0.0
     gathered = local_nnz * cols_per_launch * 4            # feature-row bytes the kernel pulls through L2 -> CU per launch
     kname = local_adj.main_kernel(kp)
-    traffic = pmc_traffic(args.graph, k, passes, kname.split("<")[0]) if not sharded and args.scale == 1.0 else None
+    full_size = args.scale == 1.0 and (args.graph != "rmat24" or args.rmat_scale == 24)
+    pmc = pmc_traffic(args.graph, k, order, passes, kname.split("<")[0]) if not sharded and full_size else None
+    traffic, pmc_hit, pmc_src = pmc if pmc else (None, None, None)
     n_cols = n if not sharded else shard.world * shard.max_rows
     compulsory = local_nnz * 8 + (local_m + 1) * 4 + n_cols * kp * 4 + local_m * kp * 4
+    # Which wall?  A column-sliced plan keeps its gathers in the XCDs' L2s (the Reddit-shaped graph: 93 % hits): the
+    # bounded fraction is L2 -> CU bytes.  An unsliced plan on a table far larger than the caches gathers from HBM /
+    # Infinity Cache: SURVEY §8(d)'s algorithmic bytes over the HBM peak IS the fraction there (<= 1 by construction).
+    # (a table that fits the 256 MiB Infinity Cache as it is never reaches HBM either: same wall, same fraction)
+    l2_bound = local_adj.num_slices > 1 or n_cols * kp * 4 <= (256 << 20)
+    frac_l2 = round(gathered / kavg / L2_PEAK, 4) if kavg > 0 else None
+    frac_alg = round(achieved / HBM_PEAK, 4)
+
+    # the same SpMM with the matrix values kept (matrices whose values do not factor as u[r]*u[c] run this pass):
+    # a second plan told to forget the factors (API, not an environment switch), a short timed loop of its own
+    weighted_ms = None
+    if not sharded and l2_bound and local_adj.has_value_factors and not check_failed:
+        adj_w = gcn_amd.CsrAdjacency(rowptr, col, val, (n, n), symmetric=True, chunk_nnz=args.chunk)
+        adj_w.plan                                                         # noqa: B018  (builds the plan)
+        adj_w.set_value_factors(None, None)
+        reps = max(3, min(args.steps, 10))
+        for _ in range(2):
+            adj_w.matmul_raw(H, out=out)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            adj_w.matmul_raw(H, out=out)
+        e1.record()
+        torch.cuda.synchronize()
+        weighted_ms = {"ms_per_spmm": round(e0.elapsed_time(e1) / reps, 4), "kernel": adj_w.main_kernel(k), "spmms_timed": reps,
+                       "what": "whole SpMM with the value stream kept (gcn_spmm_plan_set_value_factors(null, null)): what an "
+                               "adjacency whose values are not u[r]*u[c] costs on this graph"}
+        del adj_w
 
     if rank == 0:
         flops = 2.0 * nnz * k if not sim else 2.0 * local_nnz * k
+        ord_txt = {"none": "no reorder", "deg": "degree-descending order (order_deg)", "rcm": "RCM order (order_rcm)",
+                   "gorder": "Gorder (RCM then Gorder, window 3)"}[order]
+        gname = f"R-MAT scale {args.rmat_scale} (Graph500 a,b,c,d = .57,.19,.19,.05, edge factor 16)" if args.graph == "rmat24" \
+            else f"{args.graph}-shaped R-MAT graph"
         line = {
             "metric": "SpMM GFLOP/s + achieved HBM GB/s, Reddit feat=128, 1/2/4/8 MI355X",
             "value": round(flops * args.steps / elapsed / 1e9, 2),
@@ -306,12 +398,14 @@ def main():
             "dtype": "f32",
             "data": "synthetic" if not rehearsal else "synthetic; REHEARSAL (all ranks on one GPU, gloo transport) - not a metric",
             "config": {
-                "workload": (f"{args.graph}-shaped R-MAT graph, n={n}, nnz={nnz} (incl. self-loops), "
-                             f"feat={k}, fp32, no reorder; step = C = Â·H"
+                "workload": (f"{gname}, n={n}, nnz={nnz} (incl. self-loops), "
+                             f"feat={k}, fp32, {ord_txt}; step = C = Â·H"
                              + ("" if world == 1 else " per row block + exchange of the layer output")
                              + (f"; ONE GPU computing rank 0's row block of a {sim}-way partition (rows={local_m}, "
-                                f"nnz={local_nnz}), no exchange: not the headline metric" if sim else "")),
-                "n": n, "nnz": nnz, "k": k,
+                                f"nnz={local_nnz}), no exchange: not the headline metric" if sim else "")
+                             + ("" if args.graph == "reddit" and order == "none" and not sim else
+                                "; NOT the headline config (BASELINE.json metric is quoted on reddit feat=128)")),
+                "n": n, "nnz": nnz, "k": k, "order": order,
                 "parallelism": "single GPU" if world == 1 else f"1-D row partition x{world} (nnz-balanced, every rank built from its own block), {collective} per plane and layer",
                 "collective": collective, "ranks_seen": world,
                 "chunks": f"{local_adj.num_chunks} x {local_adj.chunk_size} nnz",
@@ -319,19 +413,21 @@ def main():
             "check": {"rel_err": rel_all, "tol": TOL, "rows_per_rank": int(checked), "passed": not check_failed,
                       "what": "last timed step's output vs fp64 evaluation of sampled rows (torch, gcn_amd/check.py), max over ranks"},
             "roofline": {
-                "bound": "hbm",
+                "bound": "l2" if l2_bound else "hbm",
                 "kernel": kname,
                 "slices": local_adj.num_slices,
                 # SURVEY §8(d) contract figure: one gathered feature row per non-zero charged to HBM
                 "achieved": round(achieved / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                "algorithmic_over_hbm_peak": round(achieved / HBM_PEAK, 4),
-                "algorithmic_note": "not a roofline fraction: most gathered rows are served by L2, so the contract's byte "
-                                    "count exceeds what crosses any one interface",
-                # the physically bounded fractions
-                "frac": round(gathered / kavg / L2_PEAK, 4) if kavg > 0 else None,
-                "frac_of": "L2->CU gather path: gathered feature-row bytes per launch / kernel time / 34.5 TB/s "
-                           "(MI355X_MICROARCH.md §L2) - the wall this kernel is bound by (texture addressers busy 85 %)",
-                "frac_l2": round(gathered / kavg / L2_PEAK, 4) if kavg > 0 else None,
+                "algorithmic_over_hbm_peak": frac_alg,
+                "algorithmic_note": ("not a roofline fraction here: most gathered rows are served by L2, so the contract's byte "
+                                     "count exceeds what crosses any one interface") if l2_bound else
+                                    "the table is far larger than the caches: this IS the fraction of the HBM roofline (frac)",
+                # the physically bounded fraction of the wall this kernel is bound by
+                "frac": frac_l2 if l2_bound else frac_alg,
+                "frac_of": ("L2->CU gather path: gathered feature-row bytes per launch / kernel time / 34.5 TB/s "
+                            "(MI355X_MICROARCH.md §L2) - the wall the sliced kernel is bound by (texture addressers busy 85 %)")
+                           if l2_bound else "HBM: SURVEY §8(d) algorithmic bytes per launch / kernel time / 8.0 TB/s",
+                "frac_l2": frac_l2,
                 "gathered_bytes_per_launch": int(gathered),
                 "frac_fabric": None if traffic is None or kavg <= 0 else round(traffic / kavg / FABRIC_GATHER_CEILING, 4),
                 "fabric_ceiling": "8.6 TB/s: random 256-byte-row gathers from an Infinity-Cache-resident table (MI355X_MICROARCH.md)",
@@ -346,15 +442,28 @@ def main():
                           "passes of every timed SpMM (gcn_spmm_profile_begin/_end)",
                 "traffic": traffic,
                 "traffic_GBps": None if traffic is None or kavg <= 0 else round(traffic / kavg / 1e9, 1),
+                "traffic_over_compulsory": None if traffic is None else round(traffic / compulsory, 3),
+                "l2_hit_rate": pmc_hit,
                 "traffic_source": "not collected in this run" if traffic is None else
-                "committed profile of this same command and kernel, NOT measured in this run: profiles/pmc_latest.json "
+                f"committed profile of this same command and kernel, NOT measured in this run: {pmc_src} "
                 "(separate rocprofv3 --pmc passes; FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; L2-miss bytes incl. "
                 "Infinity-Cache hits)",
+                "weighted": weighted_ms,
             },
             "gflops_kernel_only": round(2.0 * local_nnz * kp / spmm_avg / 1e9, 1) if spmm_avg > 0 else None,
         }
+        if order != "none":
+            line["config"]["ordering_seconds"] = round(order_secs, 3)
+            line["config"]["ordering_ran_on"] = order_where
+        if world > 1 or sim:
+            # what the exchange may cost before 6x at 8 GPUs is lost: 8 ranks must finish a layer in (single-GPU step / 6)
+            line["scaling_budget"] = {
+                "layer_ms_this_run": round(elapsed / args.steps * 1e3, 4),
+                "note": "a 6x aggregate at N = 8 needs (rank share + unhidden exchange) <= ms_per_step(N = 1) / 6; "
+                        "ms_per_step(N = 1) is the driver's own N = 1 run (2.86 ms in round 2 -> 0.477 ms)",
+            }
         if not sharded and not args.no_cpu_baseline and not check_failed:
-            line["cpu_baseline"] = cpu_baseline(rowptr, col, val, n, k, seed=2)
+            line["cpu_baseline"] = cpu_baseline(rowptr, col, val, n, k, H, args.graph)
         print(json.dumps(line), flush=True)
 
     if world > 1:

@@ -49,6 +49,7 @@ SIGNATURES = {
     "gcn_spmm_profile_begin": (ctypes.c_int, [_c_p, _c_i32]),
     "gcn_spmm_profile_end": (ctypes.c_int, [_c_p, _c_p, _c_p]),
     "gcn_spmm_csr_f32_oneshot": (ctypes.c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_i32, _c_i32, _c_i32, _c_i32, _c_p]),
+    "gcn_spmm_group_addressing": (_c_i32, [ctypes.c_int64, _c_i32]),
     "gcn_gather_rows_f32": (ctypes.c_int, [_c_p, _c_p, _c_p, _c_i32, _c_i32, _c_p]),
     "gcn_order_deg_device": (ctypes.c_int, [_c_p, _c_p, _c_i32, _c_i32, _c_i32, _c_i32, _c_p, _c_p]),
     "gcn_order_rcm_device": (ctypes.c_int, [_c_p, _c_p, _c_i32, _c_i32, _c_p, _c_p, _c_p]),

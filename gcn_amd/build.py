@@ -39,6 +39,16 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _digest(paths):
+    """content hash of a unit's inputs: the stamp beside every object (mtimes do not survive a snapshot copy)"""
+    import hashlib
+    h = hashlib.sha256()
+    for p in paths:
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def _compile_one(args):
     src, obj, verbose = args
     cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++20", "-fPIC", "-fvisibility=default", "-Wall",
@@ -58,17 +68,24 @@ def build(force=False, verbose=False):
     os.makedirs(DROPIN, exist_ok=True)
     hdrs = [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
     me = os.path.abspath(__file__)
-    jobs, objs = [], []
+    jobs, objs, stamps = [], [], []
     for s in SOURCES:
         src = os.path.join(CSRC, s)
         obj = os.path.join(OBJDIR, os.path.splitext(s)[0] + ".o")
         objs.append(obj)
-        if force or _stale(obj, [src, me] + hdrs):
+        want = _digest([src, me] + hdrs)
+        stamp = obj + ".sha"
+        have = open(stamp).read().strip() if os.path.exists(stamp) else ""
+        if force or not os.path.exists(obj) or have != want:
             jobs.append((src, obj, verbose))
+            stamps.append((stamp, want))
     if jobs:
         with ThreadPoolExecutor(max_workers=min(len(jobs), max(1, (os.cpu_count() or 2) - 1))) as ex:
             list(ex.map(_compile_one, jobs))
-    if force or jobs or _stale(LIB, objs):
+        for stamp, want in stamps:
+            with open(stamp, "w") as f:
+                f.write(want)
+    if force or jobs or not os.path.exists(LIB):
         cmd = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", LIB]
         if verbose:
             print(" ".join(cmd), flush=True)

@@ -340,6 +340,7 @@ static void flexspmm_group(const int* seg_rowPtr, const float* segNzCV, const in
   ga.chunk_meta = seg_rowPtr + 16;
   ga.Bp = scratch.bpad; ga.Cv = scratch.cv; ga.P = scratch.ws;
   ga.nchunks = nchunks; ga.T = kDropinT; ga.k = kc; ga.ldb = ldb;
+  ga.table_rows = (long long)g.S * ((long long)g.w + 1);
   e = gcn::launch_spmm_group(ga, st);
   if (e != hipSuccess) die("flexspmm launch", e);
   const int* fix = seg_rowPtr + (16 + 2 * (size_t)nchunks + 3) / 4 * 4;

@@ -232,6 +232,9 @@ bool sliced_for(const gcn_spmm_plan* p, int k) {
   return k > 16 && p->gather_width != 1 && gcn::pad_b_enabled() && (long long)sizeof(float) * p->n * ldb <= (768LL << 20);
 }
 
+// rows of the slice-by-slice copy of B the group kernels gather from (decides their addressing mode, spmm_group.hip)
+long long group_table_rows(const gcn_spmm_plan* p) { return (long long)p->slicing.S * ((long long)p->group.w + 1); }
+
 // would the sliced launch of a k-wide SpMM run a value-free kernel (and is the scaled copy of B worth it)?
 bool valless_pays(const gcn_spmm_plan* p, int k, int ldb) {
   // (the scaled copy of B costs 2*n*k*4 bytes of traffic whatever the matrix; the value stream it saves is
@@ -240,7 +243,7 @@ bool valless_pays(const gcn_spmm_plan* p, int k, int ldb) {
   //  profiles/r02z7_rank_share_value_free.log; below 48 per column nothing has been measured, so it stays off)
   if (!sliced_for(p, k) || !p->factors.ready() || p->panels.R != 0 || p->nnz / p->n < gcn::valless_min_per_col()) return false;
   if (p->group.vals) return false;                     // (the plan was built for the weighted pass: value-free did not pay)
-  if (p->group.ready() && gcn::spmm_group_eligible(k, ldb, nullptr, nullptr, nullptr)) return true;   // spmm_group.hip
+  if (p->group.ready() && gcn::spmm_group_eligible(k, ldb, group_table_rows(p), nullptr, nullptr, nullptr)) return true;   // spmm_group.hip
   gcn::SpmmArgs t{};                                   // the launch as the sliced branch will issue it
   t.k = k; t.nnz = p->nnz; t.n = p->n; t.nchunks_grid = p->nchunks; t.T = p->T;
   t.m = p->slicing.S * p->m; t.ldb = ldb; t.tile_cols = p->tile_cols ? p->tile_cols : 64;
@@ -259,7 +262,7 @@ bool group_plan(const gcn_spmm_plan* p) {
 // the sliced launch of a k-wide SpMM runs the WEIGHTED group kernel (values beside the stream)
 bool weighted_pass(const gcn_spmm_plan* p, int k, int ldb) {
   return sliced_for(p, k) && p->panels.R == 0 && p->group.ready() && p->group.vals &&
-         gcn::spmm_group_eligible(k, ldb, nullptr, nullptr, nullptr);
+         gcn::spmm_group_eligible(k, ldb, group_table_rows(p), nullptr, nullptr, nullptr);
 }
 
 // the value-free pass of this plan runs the group kernel (its scaled copy of B is then laid out slice by slice)
@@ -402,6 +405,7 @@ int spmm_impl(gcn_spmm_plan* p, const int32_t* rowptr, const int32_t* col, const
     ga.vals = weighted ? p->group.vals.get() : nullptr;
     ga.Bp = a.B; ga.Cv = p->cv; ga.P = p->ws;
     ga.nchunks = p->group.nchunks; ga.T = p->group.T; ga.k = k; ga.ldb = a.ldb;
+    ga.table_rows = group_table_rows(p);
     ga.store_policy = gcn::group_store();
     ga.ring = gcn::group_ring() ? 1 : 0;
     ga.merge_tiles = gcn::group_merge_tiles() ? 1 : 0;
@@ -832,16 +836,22 @@ int gcn_spmm_plan_main_kernel(const gcn_spmm_plan_t* p, int32_t k, int32_t epilo
     a.valless = valless_pays(p, k, a.ldb > 0 ? a.ldb : k);   // as spmm_impl decides
   }
   a.col16 = a.valless && p->col16.ready();
+  const int ld_eff = a.ldb > 0 ? a.ldb : a.k;
+  const bool big = gcn::spmm_group_needs_big(group_table_rows(p), ld_eff);
+  const char* bigs = big ? "true" : "false";
   if (a.valless && group_pass(p)) {
     if (gcn::group8_enabled() && a.k <= 32 && p->group.nchunks % 64 == 0)
-      snprintf(buf, (size_t)buflen, "gcn::spmm_group8_kernel<%d, %s>", p->group.T, gcn::group_ring() ? "true" : "false");
+      snprintf(buf, (size_t)buflen, "gcn::spmm_group8_kernel<%d, %s, %s>", p->group.T, gcn::group_ring() ? "true" : "false", bigs);
     else
-      snprintf(buf, (size_t)buflen, "gcn::spmm_group%s_kernel<%d, %d>", gcn::group_ring() ? "_ring" : "", p->group.T, gcn::group_store());
+      snprintf(buf, (size_t)buflen, "gcn::spmm_group%s_kernel<%d, %d, %s>", gcn::group_ring() ? "_ring" : "", p->group.T,
+               big ? 2 : gcn::group_store(), bigs);
     return GCN_OK;
   }
-  if (!a.valless && weighted_pass(p, a.k, a.ldb > 0 ? a.ldb : a.k)) {
-    if (gcn::group8_enabled() && a.k <= 32 && p->group.nchunks % 64 == 0) snprintf(buf, (size_t)buflen, "gcn::spmm_group8_weighted_kernel<%d>", p->group.T);
-    else snprintf(buf, (size_t)buflen, "gcn::spmm_group_weighted_kernel<%d, %d>", p->group.T, gcn::group_store());
+  if (!a.valless && weighted_pass(p, a.k, ld_eff)) {
+    if (gcn::group8_enabled() && a.k <= 32 && p->group.nchunks % 64 == 0)
+      snprintf(buf, (size_t)buflen, "gcn::spmm_group8_weighted_kernel<%d, %s>", p->group.T, bigs);
+    else
+      snprintf(buf, (size_t)buflen, "gcn::spmm_group_weighted_kernel<%d, %d, %s>", p->group.T, big ? 2 : gcn::group_store(), bigs);
     return GCN_OK;
   }
   gcn::describe_main_kernel(a, buf, (size_t)buflen);
@@ -893,6 +903,12 @@ int gcn_spmm_csr_f32_oneshot(const int32_t* rowptr, const int32_t* col, const fl
   a.nnz_dev = nullptr; a.nchunks_grid = p->nchunks;
   a.tile_cols = gcn::auto_tile_cols(n, k);
   return gcn::launch_spmm(a, cu, (hipStream_t)stream) == hipSuccess ? GCN_OK : GCN_ERR_HIP;
+}
+
+int32_t gcn_spmm_group_addressing(int64_t table_rows, int32_t ld_floats) {
+  if (table_rows <= 0 || ld_floats <= 0) return -1;
+  if (!gcn::spmm_group_eligible(ld_floats, ld_floats, table_rows, nullptr, nullptr, nullptr)) return -1;
+  return gcn::spmm_group_needs_big(table_rows, ld_floats) ? 1 : 0;
 }
 
 int gcn_gather_rows_f32(float* dst, const float* src, const int32_t* idx, int32_t nrows, int32_t k,

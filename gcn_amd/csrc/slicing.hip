@@ -535,7 +535,7 @@ hipError_t build_group_stream(const int* vrowptr, const int* vcol, int m, int n,
 // scaled copy of B in the group kernel's layout: slice s at rows [s*(w+1), (s+1)*(w+1)), the last one zero
 __global__ void __launch_bounds__(256)
 scale_rows_sliced_kernel(float* __restrict__ dst, const float* __restrict__ src, const float* __restrict__ rowscale,
-                         int n, int k, int ld, int S, int w) {
+                         int n, int k, int ld, int S, int w, int src_vec) {
   const int ld4 = ld >> 2;                                       // float4 per destination row
   const long long total = (long long)S * (w + 1) * ld4;
   const long long stride = (long long)gridDim.x * blockDim.x;
@@ -548,7 +548,7 @@ scale_rows_sliced_kernel(float* __restrict__ dst, const float* __restrict__ src,
     if (j < w && c < n && x < k) {
       const float u = rowscale ? rowscale[c] : 1.f;
       const float* p = src + c * k + x;
-      if ((k & 3) == 0) { const float4 t = *reinterpret_cast<const float4*>(p); v = make_float4(u * t.x, u * t.y, u * t.z, u * t.w); }
+      if (src_vec) { const float4 t = *reinterpret_cast<const float4*>(p); v = make_float4(u * t.x, u * t.y, u * t.z, u * t.w); }
       else { v.x = u * p[0]; if (x + 1 < k) v.y = u * p[1]; if (x + 2 < k) v.z = u * p[2]; if (x + 3 < k) v.w = u * p[3]; }
     }
     *reinterpret_cast<float4*>(dst + R * ld + x) = v;
@@ -558,10 +558,12 @@ scale_rows_sliced_kernel(float* __restrict__ dst, const float* __restrict__ src,
 hipError_t launch_scale_rows_sliced(float* dst, const float* src, const float* rowscale, int n, int k, int ld,
                                     int S, int w, hipStream_t s) {
   if (n <= 0 || k <= 0) return hipSuccess;
-  if (ld % 4 != 0 || ((uintptr_t)dst & 15) != 0 || ((k & 3) == 0 && ((uintptr_t)src & 15) != 0)) return hipErrorInvalidValue;
+  if (ld % 4 != 0 || ((uintptr_t)dst & 15) != 0) return hipErrorInvalidValue;
+  // 16-byte loads of the source rows when they are 16-byte aligned (k % 4 == 0 and an aligned B); scalar loads otherwise
+  const int src_vec = ((k & 3) == 0 && ((uintptr_t)src & 15) == 0) ? 1 : 0;
   long long nb = ((long long)S * (w + 1) * (ld / 4) + 255) / 256;
   if (nb > 65536) nb = 65536;
-  scale_rows_sliced_kernel<<<(int)nb, 256, 0, s>>>(dst, src, rowscale, n, k, ld, S, w);
+  scale_rows_sliced_kernel<<<(int)nb, 256, 0, s>>>(dst, src, rowscale, n, k, ld, S, w, src_vec);
   return hipGetLastError();
 }
 

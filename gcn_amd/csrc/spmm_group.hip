@@ -75,7 +75,11 @@ __device__ __forceinline__ void store_row_piece(float* dst, const float4& v) {
 // Bp: scaled copy of B, slice s at rows [s*(w+1), (s+1)*(w+1)), row w of every slice all zero
 // nchunks % 32 == 0 (the stream is padded), so every XCD owns whole waves.
 // vals (VALS only) [nchunks*T]: the matrix values in stream order, 0 at padding entries
-template <int T, int POLICY, bool VALS, bool RING>
+// BIG: the sliced copy of B is 4 GiB or more (or has 2^24 rows or more): the slice's first row is added to the table
+// pointer in 64 bits, per lane, and only the offset INSIDE the slice (< 32 768 rows x < 128 KiB) stays in 32 bits —
+// one more vector instruction per gather (add + carry instead of one add).  Without it the 32-bit byte offset
+// (entry + base) * row_bytes would wrap silently.
+template <int T, int POLICY, bool VALS, bool RING, bool BIG>
 __device__ __forceinline__ void
 group_walk(const unsigned short* __restrict__ stream, const float* __restrict__ vals, const int2* __restrict__ chunk_meta,
            const float* __restrict__ Bp, float* __restrict__ Cv, float* __restrict__ P,
@@ -99,13 +103,14 @@ group_walk(const unsigned short* __restrict__ stream, const float* __restrict__ 
   const bool fok = fcol < k;                                    // (k % 4 == 0: a float4 is all in or all out)
   const unsigned row_bytes = (unsigned)ldb * 4u;
   const unsigned foff = (unsigned)(fok ? fcol : col_tile * 64) * 4u;
-  const char* __restrict__ Bb = reinterpret_cast<const char*>(Bp);
+  const char* Bb = reinterpret_cast<const char*>(Bp);
   const size_t kk = (size_t)k;
 
   const int2 meta = chunk_meta[c];                              // one load: nothing else stands before the first gather
   const int vrow = meta.x >> 1;                                 // virtual row holding the chunk's first entry
   const bool head = meta.x & 1;                                 // ... which began in an earlier chunk
-  const int base = meta.y;                                      // first row of this chunk's slice in Bp
+  const int base = BIG ? 0 : meta.y;                            // first row of this chunk's slice in Bp
+  if constexpr (BIG) Bb += (size_t)meta.y * (size_t)row_bytes;  // (per lane: the groups of a wave can sit in different slices)
   float* ptr  = head ? P + (size_t)(2 * c) * kk + fcol : Cv + (size_t)vrow * kk + fcol;
   float* nptr = Cv + (size_t)(vrow + 1) * kk + fcol;
   bool first = true;                                            // no row of this chunk has ended yet
@@ -213,31 +218,31 @@ group_walk(const unsigned short* __restrict__ stream, const float* __restrict__ 
   }
 }
 
-template <int T, int POLICY>
+template <int T, int POLICY, bool BIG>
 __global__ void __launch_bounds__(256)
 spmm_group_kernel(const unsigned short* __restrict__ stream, const int2* __restrict__ chunk_meta,
                   const float* __restrict__ Bp, float* __restrict__ Cv, float* __restrict__ P,
                   int nchunks, int k, int col_tile, int ldb, int stream_nt, int blocks_per_tile) {
-  group_walk<T, POLICY, false, false>(stream, nullptr, chunk_meta, Bp, Cv, P, nchunks, k, col_tile, ldb, stream_nt, blocks_per_tile);
+  group_walk<T, POLICY, false, false, BIG>(stream, nullptr, chunk_meta, Bp, Cv, P, nchunks, k, col_tile, ldb, stream_nt, blocks_per_tile);
 }
 
-template <int T, int POLICY>
+template <int T, int POLICY, bool BIG>
 __global__ void __launch_bounds__(256)
 spmm_group_ring_kernel(const unsigned short* __restrict__ stream, const int2* __restrict__ chunk_meta,
                        const float* __restrict__ Bp, float* __restrict__ Cv, float* __restrict__ P,
                        int nchunks, int k, int col_tile, int ldb, int stream_nt, int blocks_per_tile) {
-  group_walk<T, POLICY, false, true>(stream, nullptr, chunk_meta, Bp, Cv, P, nchunks, k, col_tile, ldb, stream_nt, blocks_per_tile);
+  group_walk<T, POLICY, false, true, BIG>(stream, nullptr, chunk_meta, Bp, Cv, P, nchunks, k, col_tile, ldb, stream_nt, blocks_per_tile);
 }
 
 // the same walk for matrices whose values do not factor: one fp32 value per entry beside the 16-bit stream,
 // handed from the lane that loaded it to its group by the same DPP broadcast as the address (one more vector
 // instruction and four FMAs instead of two packed adds per step); Bp is then a plain (unscaled) sliced copy of B
-template <int T, int POLICY>
+template <int T, int POLICY, bool BIG>
 __global__ void __launch_bounds__(256)
 spmm_group_weighted_kernel(const unsigned short* __restrict__ stream, const float* __restrict__ vals,
                            const int2* __restrict__ chunk_meta, const float* __restrict__ Bp, float* __restrict__ Cv,
                            float* __restrict__ P, int nchunks, int k, int col_tile, int ldb, int stream_nt, int blocks_per_tile) {
-  group_walk<T, POLICY, true, false>(stream, vals, chunk_meta, Bp, Cv, P, nchunks, k, col_tile, ldb, stream_nt, blocks_per_tile);
+  group_walk<T, POLICY, true, false, BIG>(stream, vals, chunk_meta, Bp, Cv, P, nchunks, k, col_tile, ldb, stream_nt, blocks_per_tile);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -255,7 +260,7 @@ __device__ __forceinline__ int row_ror8_bcast(int v, int vrot, bool upper) {   /
   return upper ? hi : lo;
 }
 
-template <int T, bool RING, bool VALS>
+template <int T, bool RING, bool VALS, bool BIG>
 __device__ __forceinline__ void
 group8_walk(const unsigned short* __restrict__ stream, const float* __restrict__ vals, const int2* __restrict__ chunk_meta,
             const float* __restrict__ Bp, float* __restrict__ Cv, float* __restrict__ P,
@@ -275,13 +280,14 @@ group8_walk(const unsigned short* __restrict__ stream, const float* __restrict__
   const bool fok = fcol < k;
   const unsigned row_bytes = (unsigned)ldb * 4u;
   const unsigned foff = (unsigned)(fok ? fcol : 0) * 4u;
-  const char* __restrict__ Bb = reinterpret_cast<const char*>(Bp);
+  const char* Bb = reinterpret_cast<const char*>(Bp);
   const size_t kk = (size_t)k;
 
   const int2 meta = chunk_meta[c];
   const int vrow = meta.x >> 1;
   const bool head = meta.x & 1;
-  const int base = meta.y;
+  const int base = BIG ? 0 : meta.y;
+  if constexpr (BIG) Bb += (size_t)meta.y * (size_t)row_bytes;  // (as group_walk)
   float* ptr  = head ? P + (size_t)(2 * c) * kk + fcol : Cv + (size_t)vrow * kk + fcol;
   float* nptr = Cv + (size_t)(vrow + 1) * kk + fcol;
   bool first = true;
@@ -430,27 +436,38 @@ group8_walk(const unsigned short* __restrict__ stream, const float* __restrict__
   }
 }
 
-bool spmm_group_eligible(int k, int ldb, const void* B, const void* C, const void* P) {
-  const uintptr_t al = (uintptr_t)B | (uintptr_t)C | (uintptr_t)P;
-  if (ldb <= 0) ldb = k;
-  return k % 4 == 0 && ldb % 4 == 0 && (al & 15) == 0 && ldb * 4 < (1 << 24);
-}
-
-template <int T, bool RING>
+template <int T, bool RING, bool BIG>
 __global__ void __launch_bounds__(256)
 spmm_group8_kernel(const unsigned short* __restrict__ stream, const int2* __restrict__ chunk_meta,
                    const float* __restrict__ Bp, float* __restrict__ Cv, float* __restrict__ P,
                    int nchunks, int k, int ldb, int stream_nt) {
-  group8_walk<T, RING, false>(stream, nullptr, chunk_meta, Bp, Cv, P, nchunks, k, ldb, stream_nt);
+  group8_walk<T, RING, false, BIG>(stream, nullptr, chunk_meta, Bp, Cv, P, nchunks, k, ldb, stream_nt);
 }
 
 // ... and with the values beside the stream (matrices whose values do not factor); no ring: 138 VGPRs without
-template <int T>
+template <int T, bool BIG>
 __global__ void __launch_bounds__(256)
 spmm_group8_weighted_kernel(const unsigned short* __restrict__ stream, const float* __restrict__ vals,
                             const int2* __restrict__ chunk_meta, const float* __restrict__ Bp, float* __restrict__ Cv,
                             float* __restrict__ P, int nchunks, int k, int ldb, int stream_nt) {
-  group8_walk<T, false, true>(stream, vals, chunk_meta, Bp, Cv, P, nchunks, k, ldb, stream_nt);
+  group8_walk<T, false, true, BIG>(stream, vals, chunk_meta, Bp, Cv, P, nchunks, k, ldb, stream_nt);
+}
+
+// 32-bit byte offsets (entry + slice base) * row_bytes reach every row of the sliced copy?  (__umul24: both factors
+// below 2^24, and the product below 2^32.)  Otherwise the BIG variants add the slice base in 64 bits.
+bool spmm_group_needs_big(long long table_rows, int ldb) {
+  // GCN_AMD_GROUP_BIG=1 (development / tests): the 64-bit variants whatever the size
+  static const bool forced = [] { const char* e = getenv("GCN_AMD_GROUP_BIG"); return e && e[0] == '1'; }();
+  return forced || table_rows >= (1LL << 24) || table_rows * (long long)ldb * 4 >= (1LL << 32);
+}
+
+// table_rows = rows of the sliced copy the kernel gathers from, S * (w + 1) (0: unknown / not checked)
+bool spmm_group_eligible(int k, int ldb, long long table_rows, const void* B, const void* C, const void* P) {
+  const uintptr_t al = (uintptr_t)B | (uintptr_t)C | (uintptr_t)P;
+  if (ldb <= 0) ldb = k;
+  if (!(k % 4 == 0 && ldb % 4 == 0 && (al & 15) == 0 && ldb * 4 < (1 << 24))) return false;
+  // BIG: the offset inside a slice (< 32 768 rows) must still fit 32 bits
+  return !spmm_group_needs_big(table_rows, ldb) || ldb * 4 < (1 << 17);
 }
 
 // k <= 32, whole waves of eight chunks per XCD: the eight-engine kernels take the launch
@@ -458,69 +475,69 @@ bool spmm_group8_applies(const GroupArgs& a) {
   return a.narrow8 && a.k <= 32 && a.k % 4 == 0 && a.nchunks % 64 == 0;
 }
 
-hipError_t launch_spmm_group(const GroupArgs& a, hipStream_t s) {
-  if (a.nchunks <= 0 || a.k <= 0) return hipSuccess;
-  if (a.nchunks % 32 != 0 || a.k % 4 != 0) return hipErrorInvalidValue;
+namespace {
+
+template <int T, bool BIG>
+hipError_t launch_group8_t(const GroupArgs& a, int ldb, hipStream_t s) {
+  const int per_xcd = a.nchunks / 8;
+  const int stream_nt8 = (size_t)a.nchunks * (size_t)a.T * (a.vals ? 6u : 2u) > ((size_t)64 << 20) ? 1 : 0;
+  const int nb8 = 8 * ((per_xcd + 31) / 32);
+  const int2* meta = reinterpret_cast<const int2*>(a.chunk_meta);
+  if (a.vals)      spmm_group8_weighted_kernel<T, BIG><<<dim3(nb8), dim3(256), 0, s>>>(a.stream, a.vals, meta, a.Bp, a.Cv, a.P, a.nchunks, a.k, ldb, stream_nt8);
+  else if (a.ring) spmm_group8_kernel<T, true, BIG><<<dim3(nb8), dim3(256), 0, s>>>(a.stream, meta, a.Bp, a.Cv, a.P, a.nchunks, a.k, ldb, stream_nt8);
+  else             spmm_group8_kernel<T, false, BIG><<<dim3(nb8), dim3(256), 0, s>>>(a.stream, meta, a.Bp, a.Cv, a.P, a.nchunks, a.k, ldb, stream_nt8);
+  return hipGetLastError();
+}
+
+template <int T, int POLICY, bool BIG>
+hipError_t launch_group_tp(const GroupArgs& a, int ldb, hipStream_t s) {
   const int per_xcd = a.nchunks / 8;
   int nblocks = 8 * ((per_xcd + 15) / 16);
   const int tiles = (a.k + 63) / 64;
-  const int ldb = a.ldb > 0 ? a.ldb : a.k;
-  if (spmm_group8_applies(a)) {                        // k <= 32: eight 8-lane row engines per wave
-    const int stream_nt8 = (size_t)a.nchunks * (size_t)a.T * (a.vals ? 6u : 2u) > ((size_t)64 << 20) ? 1 : 0;
-    const int nb8 = 8 * ((per_xcd + 31) / 32);
-    const int2* meta = reinterpret_cast<const int2*>(a.chunk_meta);
-    switch (a.T) {
-      case 256:  if (a.vals)      spmm_group8_weighted_kernel<256><<<dim3(nb8), dim3(256), 0, s>>>(a.stream, a.vals, meta, a.Bp, a.Cv, a.P, a.nchunks, a.k, ldb, stream_nt8);
-                 else if (a.ring) spmm_group8_kernel<256, true><<<dim3(nb8), dim3(256), 0, s>>>(a.stream, meta, a.Bp, a.Cv, a.P, a.nchunks, a.k, ldb, stream_nt8);
-                 else        spmm_group8_kernel<256, false><<<dim3(nb8), dim3(256), 0, s>>>(a.stream, meta, a.Bp, a.Cv, a.P, a.nchunks, a.k, ldb, stream_nt8);
-                 break;
-      case 512:  if (a.vals)      spmm_group8_weighted_kernel<512><<<dim3(nb8), dim3(256), 0, s>>>(a.stream, a.vals, meta, a.Bp, a.Cv, a.P, a.nchunks, a.k, ldb, stream_nt8);
-                 else if (a.ring) spmm_group8_kernel<512, true><<<dim3(nb8), dim3(256), 0, s>>>(a.stream, meta, a.Bp, a.Cv, a.P, a.nchunks, a.k, ldb, stream_nt8);
-                 else        spmm_group8_kernel<512, false><<<dim3(nb8), dim3(256), 0, s>>>(a.stream, meta, a.Bp, a.Cv, a.P, a.nchunks, a.k, ldb, stream_nt8);
-                 break;
-      case 1024: if (a.vals)      spmm_group8_weighted_kernel<1024><<<dim3(nb8), dim3(256), 0, s>>>(a.stream, a.vals, meta, a.Bp, a.Cv, a.P, a.nchunks, a.k, ldb, stream_nt8);
-                 else if (a.ring) spmm_group8_kernel<1024, true><<<dim3(nb8), dim3(256), 0, s>>>(a.stream, meta, a.Bp, a.Cv, a.P, a.nchunks, a.k, ldb, stream_nt8);
-                 else        spmm_group8_kernel<1024, false><<<dim3(nb8), dim3(256), 0, s>>>(a.stream, meta, a.Bp, a.Cv, a.P, a.nchunks, a.k, ldb, stream_nt8);
-                 break;
-      case 2048: if (a.vals)      spmm_group8_weighted_kernel<2048><<<dim3(nb8), dim3(256), 0, s>>>(a.stream, a.vals, meta, a.Bp, a.Cv, a.P, a.nchunks, a.k, ldb, stream_nt8);
-                 else if (a.ring) spmm_group8_kernel<2048, true><<<dim3(nb8), dim3(256), 0, s>>>(a.stream, meta, a.Bp, a.Cv, a.P, a.nchunks, a.k, ldb, stream_nt8);
-                 else        spmm_group8_kernel<2048, false><<<dim3(nb8), dim3(256), 0, s>>>(a.stream, meta, a.Bp, a.Cv, a.P, a.nchunks, a.k, ldb, stream_nt8);
-                 break;
-      default: return hipErrorInvalidValue;
-    }
-    return hipGetLastError();
-  }
   // streams (2 or 6 bytes per entry) beyond what the L2s and a good part of the Infinity Cache hold are read non-temporally
   const int stream_nt = (size_t)a.nchunks * (size_t)a.T * (a.vals ? 6u : 2u) > ((size_t)64 << 20) ? 1 : 0;
-  const bool ring = a.ring != 0;
   // all tiles in ONE launch (merge_tiles): tile t+1 starts on the CUs that tile t's last blocks leave idle
   const int tiles_per_launch = a.merge_tiles ? tiles : 1;
   if ((long long)nblocks * tiles_per_launch >= (1LL << 31)) return hipErrorInvalidValue;
   const int blocks_per_tile = nblocks;
   nblocks *= tiles_per_launch;
+  const int2* meta = reinterpret_cast<const int2*>(a.chunk_meta);
   for (int t = 0; t < tiles; t += tiles_per_launch) {
-#define GCN_GROUP_REST reinterpret_cast<const int2*>(a.chunk_meta), a.Bp, a.Cv, a.P, a.nchunks, a.k, t, ldb, stream_nt, blocks_per_tile
-#define GCN_GROUP_PICK(KERNEL, TT, ...)                                                                  \
-      if (a.store_policy == 1)      KERNEL<TT, 1><<<dim3(nblocks), dim3(256), 0, s>>>(__VA_ARGS__);     \
-      else if (a.store_policy == 2) KERNEL<TT, 2><<<dim3(nblocks), dim3(256), 0, s>>>(__VA_ARGS__);     \
-      else                          KERNEL<TT, 0><<<dim3(nblocks), dim3(256), 0, s>>>(__VA_ARGS__);
-#define GCN_GROUP_LAUNCH(TT)                                                                             \
-      if (a.vals) { GCN_GROUP_PICK(spmm_group_weighted_kernel, TT, a.stream, a.vals, GCN_GROUP_REST) }   \
-      else if (ring) { GCN_GROUP_PICK(spmm_group_ring_kernel, TT, a.stream, GCN_GROUP_REST) }            \
-      else        { GCN_GROUP_PICK(spmm_group_kernel, TT, a.stream, GCN_GROUP_REST) }                    \
-      break;
-    switch (a.T) {
-      case 256:  GCN_GROUP_LAUNCH(256)
-      case 512:  GCN_GROUP_LAUNCH(512)
-      case 1024: GCN_GROUP_LAUNCH(1024)
-      case 2048: GCN_GROUP_LAUNCH(2048)
-      default: return hipErrorInvalidValue;
-    }
-#undef GCN_GROUP_LAUNCH
-#undef GCN_GROUP_PICK
-#undef GCN_GROUP_REST
+    if (a.vals)
+      spmm_group_weighted_kernel<T, POLICY, BIG><<<dim3(nblocks), dim3(256), 0, s>>>(a.stream, a.vals, meta, a.Bp, a.Cv, a.P, a.nchunks, a.k, t, ldb, stream_nt, blocks_per_tile);
+    else if (a.ring)
+      spmm_group_ring_kernel<T, POLICY, BIG><<<dim3(nblocks), dim3(256), 0, s>>>(a.stream, meta, a.Bp, a.Cv, a.P, a.nchunks, a.k, t, ldb, stream_nt, blocks_per_tile);
+    else
+      spmm_group_kernel<T, POLICY, BIG><<<dim3(nblocks), dim3(256), 0, s>>>(a.stream, meta, a.Bp, a.Cv, a.P, a.nchunks, a.k, t, ldb, stream_nt, blocks_per_tile);
   }
   return hipGetLastError();
+}
+
+template <int T>
+hipError_t launch_group_t(const GroupArgs& a, int ldb, bool big, hipStream_t s) {
+  if (spmm_group8_applies(a)) return big ? launch_group8_t<T, true>(a, ldb, s) : launch_group8_t<T, false>(a, ldb, s);
+  if (big) return launch_group_tp<T, 2, true>(a, ldb, s);            // (the store policy is a tuning knob: BIG keeps the default)
+  if (a.store_policy == 1) return launch_group_tp<T, 1, false>(a, ldb, s);
+  if (a.store_policy == 2) return launch_group_tp<T, 2, false>(a, ldb, s);
+  return launch_group_tp<T, 0, false>(a, ldb, s);
+}
+
+}  // namespace
+
+hipError_t launch_spmm_group(const GroupArgs& a, hipStream_t s) {
+  if (a.nchunks <= 0 || a.k <= 0) return hipSuccess;
+  if (a.nchunks % 32 != 0 || a.k % 4 != 0) return hipErrorInvalidValue;
+  const int ldb = a.ldb > 0 ? a.ldb : a.k;
+  if (a.table_rows <= 0) return hipErrorInvalidValue;                 // (the addressing mode depends on it)
+  const bool big = spmm_group_needs_big(a.table_rows, ldb);
+  if (big && ldb * 4 >= (1 << 17)) return hipErrorInvalidValue;
+  switch (a.T) {
+    case 256:  return launch_group_t<256>(a, ldb, big, s);
+    case 512:  return launch_group_t<512>(a, ldb, big, s);
+    case 1024: return launch_group_t<1024>(a, ldb, big, s);
+    case 2048: return launch_group_t<2048>(a, ldb, big, s);
+    default: return hipErrorInvalidValue;
+  }
 }
 
 }  // namespace gcn

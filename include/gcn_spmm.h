@@ -191,6 +191,13 @@ int gcn_spmm_csr_f32_oneshot(const int32_t* rowptr_dev, const int32_t* col_dev,
                      const float* val_dev, const float* B_dev, float* C_dev,
                      int32_t m, int32_t n, int32_t nnz, int32_t k, void* stream);
 
+/* How the group kernels (csrc/spmm_group.hip) address a slice-by-slice copy of B with `table_rows` rows of
+ * `ld_floats` floats: 0 = 32-bit byte offsets (table below 4 GiB and 2^24 rows), 1 = the slice base is added in
+ * 64 bits (any size), -1 = not served by them (rows of 128 KiB or more in a table that needs 64 bits, or a
+ * stride that is no multiple of 4 floats): such a plan runs the four-per-gather / one-per-gather kernels.
+ * Host arithmetic only; the reference has no counterpart (its `int addr = row*k`, flexspmm.cu:67, wraps). */
+int32_t gcn_spmm_group_addressing(int64_t table_rows, int32_t ld_floats);
+
 /* ------------------------------------------------------------------------- */
 /* (1b) feature-row permutation  dst[r,:] = src[idx[r],:]                     */
 /*      replaces flexspmm_v9_permuteX / put_back / permutate()                */

@@ -79,6 +79,23 @@ def test_reorder_entry_points_validate_input():
     assert lib.gcn_csr_apply_rank(p(rp), p(ci), p(va), 2, 2, p(bad_rank), None) == 1
 
 
+def test_group_kernel_addressing_rule_at_the_4gib_boundary():
+    """host-only: the group kernels keep (entry + slice base) * row_bytes in 32 bits only while the sliced copy of B
+    stays below 4 GiB and 2^24 rows; past either bound the slice base is added in 64 bits (the BIG variants), and a
+    table that needs 64 bits with rows of 128 KiB or more is not served by them at all (n = 8 M, k = 128
+    and n = 2.4 M, k = 512 used to wrap silently)."""
+    f = gcn_amd.load_library().gcn_spmm_group_addressing
+    assert f(232965 + 15, 128) == 0                              # Reddit-shaped, k = 128: 119 MB
+    rows_4g_k128 = (1 << 32) // 512                              # 8 388 608 rows of 512 bytes = exactly 4 GiB
+    assert f(rows_4g_k128 - 1, 128) == 0 and f(rows_4g_k128, 128) == 1
+    rows_4g_k512 = (1 << 32) // 2048                             # 2 097 152 rows of 2 KiB
+    assert f(rows_4g_k512 - 1, 512) == 0 and f(rows_4g_k512, 512) == 1
+    assert f(2449029 + 75, 512) == 1                             # products-shaped n at k = 512: 5 GB
+    assert f((1 << 24) - 1, 16) == 0 and f(1 << 24, 16) == 1     # the 24-bit multiplier's row bound
+    assert f(1 << 24, 32768) == -1 and f(1000, 32768) == 0       # 128 KiB rows: only while 32 bits reach the table
+    assert f(1000, 126) == -1 and f(0, 128) == -1                # stride not a multiple of 4 floats; no table
+
+
 def test_csr2tile_packing_respects_caller_capacities():
     """host-only drop-in: seg_rowPtr nnz ints, segNzCV 2*nnz floats, segVoMap nnz ints,
     grouped_tailSeg / next_seg exactly 256 ints (gcn6.py:334-339; reference defect D2 wrote 257)"""

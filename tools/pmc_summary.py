@@ -31,7 +31,10 @@ def main():
     ap.add_argument("--launches-per-spmm", type=int, default=1)
     ap.add_argument("--algorithmic-bytes-per-launch", type=int, default=0)
     ap.add_argument("--kernel", default="spmm_chunk_kernel")
+    ap.add_argument("--order", default="none")
+    ap.add_argument("--source", default="", help="where the raw counter tables of this summary are kept (profiles/...)")
     ap.add_argument("--out", required=True)
+    ap.add_argument("--merge-into", default="", help="profiles/pmc_latest.json: replace the entry of this (graph, k, order)")
     args = ap.parse_args()
 
     agg = collections.defaultdict(list)
@@ -48,7 +51,8 @@ def main():
     fetch = 2.0 * avg["FETCH_SIZE"] * 1024
     write = avg["WRITE_SIZE"] * 1024
     out = {
-        "graph": args.graph, "k": args.k, "launches_per_spmm": args.launches_per_spmm,
+        "graph": args.graph, "k": args.k, "order": args.order, "launches_per_spmm": args.launches_per_spmm,
+        "source": args.source or args.out,
         "kernel": sorted(names),
         "counters_avg_per_launch": avg,
         "launches_seen": {c: len(v) for c, v in agg.items()},
@@ -64,6 +68,15 @@ def main():
     }
     json.dump(out, open(args.out, "w"), indent=1)
     print(json.dumps(out, indent=1))
+    if args.merge_into:
+        try:
+            d = json.load(open(args.merge_into))
+        except (OSError, ValueError):
+            d = {}
+        entries = d.get("entries", [d] if d.get("graph") else [])
+        entries = [e for e in entries if (e.get("graph"), e.get("k"), e.get("order", "none")) != (args.graph, args.k, args.order)]
+        entries.append(out)
+        json.dump({"entries": entries}, open(args.merge_into, "w"), indent=1)
 
 
 if __name__ == "__main__":
