@@ -161,6 +161,9 @@ def main():
     ap.add_argument("--gather-width", type=int, default=-1,
                     help="debug: non-zeros per gather instruction of the 64-column kernel (0 auto, 1, 4)")
     ap.add_argument("--blocks-per-cu", type=int, default=0, help="debug: persistent-grid blocks per CU (1..8)")
+    ap.add_argument("--no-prelaid", action="store_true",
+                    help="debug: N > 1 / --sim-world: every layer re-lays its input (scaled copy of B per plane and layer) "
+                         "instead of writing the next layer's pre-laid input in the epilogue")
     ap.add_argument("--no-plane-streams", action="store_true",
                     help="debug: N > 1 / --sim-world: all column planes on one stream (default: one stream per plane)")
     ap.add_argument("--sim-world", type=int, default=0,
@@ -204,8 +207,8 @@ def main():
         sys.exit("bench.py: the row-sharded path runs the reddit / papers100m graphs un-renumbered")
     order_secs, order_where = 0.0, ""
 
-    def make_local(rp, ci, va, shape):
-        return gcn_amd.CsrAdjacency(rp, ci, va, shape, chunk_nnz=args.chunk)
+    def make_local(rp, ci, va, shape, slices="auto"):
+        return gcn_amd.CsrAdjacency(rp, ci, va, shape, chunk_nnz=args.chunk, slices=slices)
 
     # ---- inputs ------------------------------------------------------------------------------
     rowptr = col = val = None
@@ -241,26 +244,26 @@ def main():
             lrp, lcol, lval, n, bounds, u, nnz = graphgen.make_graph_row_block(
                 args.graph, part_world, part_rank, device=dev, seed=1, scale=args.scale)
         shard = RowShardedAdjacency.from_row_block(lrp, lcol, lval, bounds, part_rank, part_world, make_local,
-                                                   value_factor=u, total_nnz=nnz, exchange=args.exchange)
+                                                   value_factor=u, total_nnz=nnz, exchange=args.exchange,
+                                                   prelaid=False if args.no_prelaid else "auto")
         del lcol, u
         if sim:
             shard.collective = False
         # column planes of 64: the exchange of one plane overlaps the SpMM of the next
         pipe = PipelinedAggregation(shard, k, dev, plane_cols=64, streams=False if args.no_plane_streams else None)
 
-        def fill(p, buf):                 # features exist in the padded layout only: every rank fills ITS rows,
+        def fill(p, buf):                 # features exist in the exchange layout only: every rank fills ITS rows,
             g = torch.Generator(device=dev)   # one exchange assembles the layer input
             g.manual_seed(1000 * (shard.rank + 1) + p)
-            lo_p = shard.rank * shard.max_rows
-            buf[lo_p: lo_p + shard.rows] = torch.randn((shard.rows, buf.shape[1]), generator=g, device=dev)
+            # (pre-laid layout: the buffer holds diag(u)·H — any values do as the input of the first layer)
+            buf[shard.buffer_rows_of_local_rows(dev)] = torch.randn((shard.rows, buf.shape[1]), generator=g, device=dev)
             if sim:                       # one GPU standing in for rank 0 of W: the peers' rows are made up locally
                 g.manual_seed(7 + p)
                 for q in range(1, shard.world):
-                    lq = q * shard.max_rows
-                    rows_q = int(shard.bounds[q + 1] - shard.bounds[q])
-                    buf[lq: lq + rows_q] = torch.randn((rows_q, buf.shape[1]), generator=g, device=dev)
+                    idx = shard.buffer_rows_of_rank(q, dev)
+                    buf[idx] = torch.randn((idx.numel(), buf.shape[1]), generator=g, device=dev)
             elif world > 1:
-                shard._exchange(buf, buf[lo_p: lo_p + shard.max_rows], None, False)
+                shard._exchange(buf, shard._slot(buf), None, False)
         pipe.load_padded_block(fill)
         if world > 1 or sim:
             # One stream + one operator per plane (PipelinedAggregation): the tail kernels and launch gaps of
@@ -318,15 +321,13 @@ def main():
     if not sharded:
         rel, checked = sampled_rows_rel_err(rowptr, col, val, H, out, sel)
     else:
-        la = shard._local_args
+        op_rp, op_col, op_val = shard.as_buffer_operator()      # the layer as a map between exchange buffers
+        own = shard.buffer_rows_of_local_rows(dev)
         rel, checked = 0.0, 0
-        c0 = 0
-        lo_p = shard.rank * shard.max_rows
         for p, w in enumerate(pipe.widths):                   # plane by plane: Â·(plane of the last layer's input)
-            got = pipe.src[p][lo_p: lo_p + shard.rows]
-            r_p, checked = sampled_rows_rel_err(la[0], la[1], la[2], last_in[p], got, sel)
+            got = pipe.src[p].index_select(0, own)
+            r_p, checked = sampled_rows_rel_err(op_rp, op_col, op_val, last_in[p], got, sel)
             rel = max(rel, r_p)
-            c0 += w
         del last_in
     verdict = torch.tensor([rel], dtype=torch.float64, device=dev)
     if world > 1:
@@ -405,9 +406,10 @@ def main():
                                 f"nnz={local_nnz}), no exchange: not the headline metric" if sim else "")
                              + ("" if args.graph == "reddit" and order == "none" and not sim else
                                 "; NOT the headline config (BASELINE.json metric is quoted on reddit feat=128)")),
-                "n": n, "nnz": nnz, "k": k, "order": order,
+                "graph": args.graph, "n": n, "nnz": nnz, "k": k, "order": order,
                 "parallelism": "single GPU" if world == 1 else f"1-D row partition x{world} (nnz-balanced, every rank built from its own block), {collective} per plane and layer",
                 "collective": collective, "ranks_seen": world,
+                "prelaid": bool(sharded and shard.prelaid),
                 "chunks": f"{local_adj.num_chunks} x {local_adj.chunk_size} nnz",
             },
             "check": {"rel_err": rel_all, "tol": TOL, "rows_per_rank": int(checked), "passed": not check_failed,

@@ -12,7 +12,10 @@ DROPIN_DIR = os.path.join(_HERE, "dropin")
 
 
 class GcnAmdError(RuntimeError):
-    pass
+    status = None            # the C-ABI status code when the error came from a call (include/gcn_spmm.h), else None
+
+
+ERR_NOT_FACTORED = 6         # GCN_ERR_NOT_FACTORED
 
 
 _c_i32 = ctypes.c_int32
@@ -49,6 +52,9 @@ SIGNATURES = {
     "gcn_spmm_profile_begin": (ctypes.c_int, [_c_p, _c_i32]),
     "gcn_spmm_profile_end": (ctypes.c_int, [_c_p, _c_p, _c_p]),
     "gcn_spmm_csr_f32_oneshot": (ctypes.c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_i32, _c_i32, _c_i32, _c_i32, _c_p]),
+    "gcn_spmm_plan_prelaid_layout": (ctypes.c_int, [_c_p, _c_i32, _c_p, _c_p, _c_p, _c_p]),
+    "gcn_spmm_csr_f32_prelaid": (ctypes.c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i32, _c_i32, _c_p]),
+    "gcn_spmm_auto_slices": (_c_i32, [ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, _c_i32]),
     "gcn_spmm_group_addressing": (_c_i32, [ctypes.c_int64, _c_i32]),
     "gcn_gather_rows_f32": (ctypes.c_int, [_c_p, _c_p, _c_p, _c_i32, _c_i32, _c_p]),
     "gcn_order_deg_device": (ctypes.c_int, [_c_p, _c_p, _c_i32, _c_i32, _c_i32, _c_i32, _c_p, _c_p]),
@@ -103,4 +109,6 @@ def load(path=None):
 def check(status, what):
     if status != 0:
         msg = load().gcn_status_string(status).decode()
-        raise GcnAmdError(f"{what}: {msg} (status {status})")
+        err = GcnAmdError(f"{what}: {msg} (status {status})")
+        err.status = int(status)
+        raise err

@@ -1,7 +1,10 @@
 // api_dropin.cpp — the reference's own symbols with identical argument lists (pygcn/gcn6.py:21-25 binds them by
 // ctypes): dfs / gorder / perm_apply / rabbit (renumber.so), csr2tile (tile.so), flexspmm (flexspmm.so), permutate
-// (permutate.so), cuspmm (cuspmm.so).  All `void`, no status: a failure prints to stderr and aborts, so it is
-// never silent (the reference only prints cuSPARSE errors, cuspmm.cu:3-21).  Contract: include/gcn_spmm.h (2).
+// (permutate.so), cuspmm (cuspmm.so).  All `void`, no status — the reference's convention is print-and-go-on
+// (cuspmm.cu:3-21 prints cuSPARSE errors, nothing else is checked).  Here a failure prints one line to stderr that
+// starts with "libgcnspmm:" and RETURNS with the caller's output buffers untouched (C stays the zero matrix gcn6
+// hands over, gcn6.py:37; vomp / the CSR stay as they were), so it is never silent and the Python process lives
+// on in a state that can be diagnosed.  Contract: include/gcn_spmm.h (2).
 #include "plan.h"
 
 #include <algorithm>
@@ -9,6 +12,8 @@
 #include <cstdlib>
 #include <cmath>
 #include <cstring>
+#include <set>
+#include <tuple>
 #include <utility>
 #include <vector>
 
@@ -20,7 +25,6 @@ using gcn::auto_chunk_nnz;
 using gcn::auto_slices;
 using gcn::auto_tile_cols;
 using gcn::cu_count_cached;
-using gcn::die;
 using gcn::pad_b_enabled;
 using gcn::padded_ldb;
 using gcn::verbose;
@@ -36,43 +40,42 @@ static void apply_and_emit(int* rowPtr, int* col, float* vals, int* vomp, int n,
   for (int i = 0; i < n; ++i) vomp[rank[i]] = i;     // C ABI returns new -> old
 }
 
-static void check_csr_or_die(const char* fn, int* rowPtr, int* col, int n, int nnz) {
-  if (!csr_ok(rowPtr, col, n, nnz)) {
-    std::fprintf(stderr, "libgcnspmm: %s: malformed CSR input (n=%d nnz=%d)\n", fn, n, nnz);
-    std::abort();
-  }
+static bool csr_checked(const char* fn, int* rowPtr, int* col, int n, int nnz) {
+  if (csr_ok(rowPtr, col, n, nnz)) return true;
+  std::fprintf(stderr, "libgcnspmm: %s: malformed CSR input (n=%d nnz=%d); nothing done\n", fn, n, nnz);
+  return false;
 }
 
 void dfs(int* rowPtr, int* col, float* vals, int* vomp, int m, int n, int nnz) {
   (void)m;
-  check_csr_or_die("dfs", rowPtr, col, n, nnz);
+  if (!csr_checked("dfs", rowPtr, col, n, nnz)) return;
   gcn::reorder::Csr g{rowPtr, col, n, nnz};
   apply_and_emit(rowPtr, col, vals, vomp, n, nnz, gcn::reorder::order_dfs(g));
 }
 
 void gorder(int* rowPtr, int* col, float* vals, int* vomp, int m, int n, int nnz) {
-  check_csr_or_die("gorder", rowPtr, col, m, nnz);
   (void)n;
+  if (!csr_checked("gorder", rowPtr, col, m, nnz)) return;
   gcn::reorder::Csr g{rowPtr, col, m, nnz};
   bool ok = true;
   auto rank = gcn::reorder::order_gorder_complete(g, 3, &ok);      // window 3: renumber.cu:176
   if (!ok) {
     std::fprintf(stderr, "libgcnspmm: gorder: graph has isolated vertices in the heap index "
-                         "range; the reference's behaviour is undefined for it\n");
-    std::abort();
+                         "range; the reference's behaviour is undefined for it; nothing done\n");
+    return;
   }
   apply_and_emit(rowPtr, col, vals, vomp, m, nnz, rank);
 }
 
 void perm_apply(int* rowPtr, int* col, float* vals, int* vomp, int m, int n, int nnz) {
   (void)m;
-  check_csr_or_die("perm_apply", rowPtr, col, n, nnz);
+  if (!csr_checked("perm_apply", rowPtr, col, n, nnz)) return;
   std::vector<gcn::reorder::u64> rank(n, (gcn::reorder::u64)n);
   for (int v = 0; v < n; ++v) {
     const int old = vomp[v];
     if (old < 0 || old >= n || rank[old] != (gcn::reorder::u64)n) {       // renumber.cu:251
-      std::fprintf(stderr, "libgcnspmm: perm_apply: vomp is not a permutation\n");
-      std::abort();
+      std::fprintf(stderr, "libgcnspmm: perm_apply: vomp is not a permutation; nothing done\n");
+      return;
     }
     rank[old] = v;
   }
@@ -80,7 +83,7 @@ void perm_apply(int* rowPtr, int* col, float* vals, int* vomp, int m, int n, int
 }
 
 void rabbit(int* rowPtr, int* col, float* vals, int* vomp, int m, int n, int nnz) {
-  check_csr_or_die("rabbit", rowPtr, col, n, nnz);
+  if (!csr_checked("rabbit", rowPtr, col, n, nnz)) return;
   gcn::reorder::Csr g{rowPtr, col, n, nnz};
   auto vo = gcn::reorder::order_rabbit_vomp(g, verbose());
   for (int i = 0; i < n; ++i) vomp[i] = vo[i];
@@ -92,8 +95,13 @@ void rabbit(int* rowPtr, int* col, float* vals, int* vomp, int m, int n, int nnz
 //
 // Packed layout written by csr2tile into the caller's buffers (gcn6.py:334-339;
 // after the call gcn6 shrinks seg_rowPtr to 9*n_segs and segVoMap to 8*n_segs
-// ints and copies everything to the device, gcn6.py:353-366):
-//   n_segs[0]      = nnz / 9                      (so 9*n_segs <= nnz capacity)
+// ints and copies everything to the device, gcn6.py:353-366).  n_segs is the only
+// scalar that travels from csr2tile to flexspmm, so it carries what flexspmm must
+// know on the HOST ("any private format must encode its sizes through
+// n_segs"):
+//   n_segs[0]      = nnz / 9, minus one when needed so that its lowest bit says
+//                    "the values are u[r]*u[c]" (9*n_segs <= nnz capacity either way)
+// Plain format (graphs that do not qualify for column slicing):
 //   seg_rowPtr     = rowPtr[0..m]                 (needs m+1 <= 9*n_segs)
 //   segVoMap       = chunk_row[0..nchunks)        (needs nchunks <= 8*n_segs)
 //   segNzCV[0..nnz)      = column indices, int32 bit patterns (exact for any n,
@@ -112,86 +120,102 @@ static int dropin_T(int n_segs) { return auto_chunk_nnz(9LL * n_segs, 256); }
 // packs the slice-major 15-bit stream, its chunk metadata and the list of cut rows straight into the caller's
 // buffers, and flexspmm runs the same kernels as gcn_spmm_csr_f32 on a plan (value-free when the values are
 // u[r]*u[c], which csr2tile checks on the host with the plan API's 4-ulp rule; with the values beside the stream
-// otherwise).
-//   seg_rowPtr[0..16)   header {magic, S, T, w, nchunks, nfix, value_free, total entries, nnz}
-//   seg_rowPtr[16..)    chunk_meta (int2 per chunk), then the fix list (int4 per cut row, 16-byte aligned)
-//   segNzCV             stream (u16 per entry, lane-major runs of 64), then — 16-byte aligned — the values
-//                       (fp32 per entry, same order; absent when value-free)
-//   segVoMap[0..n)      u (fp32 bit patterns) when value-free
-// flexspmm reads the 64-byte header back (one small synchronous copy per call) — the chunk count depends on the
-// padding and cannot be derived from (m, n, n_segs) alone.
+// otherwise).  Every offset is a pure function of (m, n, n_segs):
+//   seg_rowPtr[0..16)          header {magic, S, T, w, nchunks, nfix, value_free, total entries, nnz}
+//   seg_rowPtr[16..)           chunk_meta (int2 per chunk; room for nchunks_ub)
+//   seg_rowPtr[fix_off..)      the fix list (int4 per cut row), fix_off = 16 + 2*nchunks_ub rounded up to 4
+//   segNzCV[0..)               stream (u16 per entry, lane-major runs of 64)
+//   segNzCV[val_off..)         the values (fp32 per entry, same order; absent when value-free), val_off = the
+//                              stream's upper bound rounded up to 16 bytes
+//   segVoMap[0..n)             u (fp32 bit patterns) when value-free
+// flexspmm never reads the buffers on the host in steady state: the chunk and cut-row counts (which depend on the
+// padding) are read ON THE DEVICE by dropin_guard_kernel, which also refuses buffers this library did not pack;
+// the grids are sized from the upper bounds.  The FIRST call on a given set of buffers reads the 64-byte header
+// once, synchronously, to be able to say so on stderr; every later call only enqueues kernels, as the reference's
+// flexspmm does (flexspmm.cu:497-540) — no stream drain per layer, and capturable.
 // ---------------------------------------------------------------------------
 namespace {
 constexpr int kDropinMagic = 0x47434E47;            // "GCNG"
 constexpr int kDropinT = 512;
-struct DropinGroup { int S, w; long long total_ub, nchunks_ub; };
+struct DropinGroup { int S, w, nchunks_ub; long long total_ub; size_t fix_off, val_off; };
 
 long long dropin_phys(long long p) {                // group_phys of slicing.hip: lane-major runs of 64 entries
   const int r = (int)(p & 63);
   return (p & ~63LL) + (r & 15) * 4 + (r >> 4);
 }
 
-// pure function of (m, n, n_segs): does the pair use the group format, and with how many slices?
+// pure function of (m, n, n_segs): does the pair use the group format, with how many slices, and where does
+// everything live in the caller's buffers?
 bool dropin_group(int m, int n, int n_segs, DropinGroup* g) {
-  if (!gcn::dropin_group_format_enabled() || m != n) return false;
-  const long long nnz_lb = 9LL * n_segs, nnz_ub = 9LL * n_segs + 8;
+  if (!gcn::dropin_group_format_enabled() || m != n || n_segs <= 0) return false;
+  const long long nnz_lb = 9LL * n_segs, nnz_ub = 9LL * n_segs + 17;       // (n_segs may be nnz/9 - 1)
   const int S = auto_slices(m, n, nnz_lb, true);
   if (S <= 1) return false;
   const int w = (n + S - 1) / S;
   if (w > 32767) return false;
   // entries: the non-zeros, one padding entry per empty virtual row (at most S*m), every slice padded to whole
   // chunks and the total to 64 chunks
-  const long long total_ub = (nnz_ub + (long long)S * m + (long long)(S + 64) * kDropinT + 63) / 64 * 64;
-  const long long nchunks_ub = total_ub / kDropinT + 1;
+  const long long total_ub = (nnz_ub + (long long)S * m + (long long)(S + 64) * kDropinT + 63) / (64LL * kDropinT) * (64LL * kDropinT)
+                             + 64LL * kDropinT;
+  const long long nchunks_ub = total_ub / kDropinT;                        // (a multiple of 64)
   if (total_ub >= (1LL << 31)) return false;
   if (((total_ub * 2 + 15) / 16 * 16) + total_ub * 4 > 8 * nnz_lb) return false;      // segNzCV: 2*nnz floats
   if (16 + 2 * nchunks_ub + 4 + 4 * nchunks_ub > 9LL * n_segs) return false;            // seg_rowPtr: 9*n_segs ints
   if (n > 8LL * n_segs) return false;                                                   // segVoMap: 8*n_segs ints
-  g->S = S; g->w = w; g->total_ub = total_ub; g->nchunks_ub = nchunks_ub;
+  g->S = S; g->w = w; g->total_ub = total_ub; g->nchunks_ub = (int)nchunks_ub;
+  g->fix_off = (16 + 2 * (size_t)nchunks_ub + 3) / 4 * 4;
+  g->val_off = ((size_t)total_ub * 2 + 15) / 16 * 4;                                    // (in floats, 16-byte aligned)
   return true;
 }
 
-// the host twin of build_group_stream (slicing.hip); rows must be column-sorted (sorted here if not)
-void dropin_pack_group(const int* rowPtr, const int* colIdx, const float* vals, int m, int n, int nnz,
-                       const DropinGroup& g, int* segVoMap, int* seg_rowPtr, float* segNzCV, int n_segs) {
+// column-sorted rows (the reference's pipeline hands them over sorted, renumber.cu:105-117; a sorted copy is made if not)
+struct SortedCsr {
+  const int* col; const float* val;
+  std::vector<int> col_own; std::vector<float> val_own;
+};
+void sort_rows(const int* rowPtr, const int* colIdx, const float* vals, int m, int nnz, SortedCsr* out) {
+  out->col = colIdx; out->val = vals;
+  bool sorted = true;
+  for (int r = 0; r < m && sorted; ++r)
+    for (int e = rowPtr[r] + 1; e < rowPtr[r + 1]; ++e)
+      if (colIdx[e] < colIdx[e - 1]) { sorted = false; break; }
+  if (sorted) return;
+  out->col_own.assign(colIdx, colIdx + nnz);
+  out->val_own.assign(vals, vals + nnz);
+  std::vector<std::pair<int, float>> row;
+  for (int r = 0; r < m; ++r) {
+    row.clear();
+    for (int e = rowPtr[r]; e < rowPtr[r + 1]; ++e) row.emplace_back(colIdx[e], vals[e]);
+    std::stable_sort(row.begin(), row.end(), [](const auto& x, const auto& y) { return x.first < y.first; });
+    for (size_t i = 0; i < row.size(); ++i) { out->col_own[(size_t)rowPtr[r] + i] = row[i].first; out->val_own[(size_t)rowPtr[r] + i] = row[i].second; }
+  }
+  out->col = out->col_own.data(); out->val = out->val_own.data();
+}
+
+// values u[r]*u[c]?  (rank1_diag_kernel / rank1_check_kernel of slicing.hip, on the host) — u is filled when they are
+bool values_factor(const int* rowPtr, const int* colIdx, const float* vals, int m, int n, std::vector<float>* u) {
+  if (m != n) return false;
+  u->assign((size_t)n, 0.f);
+  for (int r = 0; r < n; ++r) {
+    const int* lo = std::lower_bound(colIdx + rowPtr[r], colIdx + rowPtr[r + 1], r);
+    if (lo < colIdx + rowPtr[r + 1] && *lo == r && vals[lo - colIdx] > 0.f) (*u)[r] = (float)std::sqrt((double)vals[lo - colIdx]);
+    else return false;
+  }
+  for (int r = 0; r < n; ++r)
+    for (int e = rowPtr[r]; e < rowPtr[r + 1]; ++e) {
+      const float want = (*u)[r] * (*u)[colIdx[e]];
+      if (!(std::fabs(vals[e] - want) <= 4.8e-7f * std::fabs(vals[e]))) return false;
+    }
+  return true;
+}
+
+// the host twin of build_group_stream (slicing.hip); rows column-sorted
+bool dropin_pack_group(const int* rowPtr, const int* colIdx, const float* vals, int m, int n, int nnz,
+                       const DropinGroup& g, bool value_free, const std::vector<float>& u, int* segVoMap, int* seg_rowPtr,
+                       float* segNzCV, int n_segs) {
   const int S = g.S, w = g.w, T = kDropinT;
   const long long vm = (long long)S * m;
-  // the reference's pipeline hands over column-sorted rows (renumber.cu:105-117); work on a sorted copy if not
-  std::vector<int> col_sorted;
-  std::vector<float> val_sorted;
-  {
-    bool sorted = true;
-    for (int r = 0; r < m && sorted; ++r)
-      for (int e = rowPtr[r] + 1; e < rowPtr[r + 1]; ++e)
-        if (colIdx[e] < colIdx[e - 1]) { sorted = false; break; }
-    if (!sorted) {
-      col_sorted.assign(colIdx, colIdx + nnz);
-      val_sorted.assign(vals, vals + nnz);
-      std::vector<std::pair<int, float>> row;
-      for (int r = 0; r < m; ++r) {
-        row.clear();
-        for (int e = rowPtr[r]; e < rowPtr[r + 1]; ++e) row.emplace_back(colIdx[e], vals[e]);
-        std::stable_sort(row.begin(), row.end(), [](const auto& x, const auto& y) { return x.first < y.first; });
-        for (size_t i = 0; i < row.size(); ++i) { col_sorted[(size_t)rowPtr[r] + i] = row[i].first; val_sorted[(size_t)rowPtr[r] + i] = row[i].second; }
-      }
-      colIdx = col_sorted.data();
-      vals = val_sorted.data();
-    }
-  }
-  // 1. values u[r]*u[c]?  (rank1_diag_kernel / rank1_check_kernel of slicing.hip)
-  std::vector<float> u((size_t)n, 0.f);
-  bool value_free = true;
-  for (int r = 0; r < n && value_free; ++r) {
-    const int* lo = std::lower_bound(colIdx + rowPtr[r], colIdx + rowPtr[r + 1], r);
-    if (lo < colIdx + rowPtr[r + 1] && *lo == r && vals[lo - colIdx] > 0.f) u[r] = (float)std::sqrt((double)vals[lo - colIdx]);
-    else value_free = false;
-  }
-  for (int r = 0; r < n && value_free; ++r)
-    for (int e = rowPtr[r]; e < rowPtr[r + 1]; ++e) {
-      const float want = u[r] * u[colIdx[e]];
-      if (!(std::fabs(vals[e] - want) <= 4.8e-7f * std::fabs(vals[e]))) { value_free = false; break; }
-    }
-  // 2. entries per virtual row (at least one), positions in the padded stream
+  // 1. entries per virtual row (at least one), positions in the padded stream
   std::vector<int> cnt((size_t)vm, 0);
   for (int r = 0; r < m; ++r)
     for (int e = rowPtr[r]; e < rowPtr[r + 1]; ++e) ++cnt[(size_t)(colIdx[e] / w) * m + r];
@@ -207,12 +231,12 @@ void dropin_pack_group(const int* rowPtr, const int* colIdx, const float* vals, 
   }
   const long long total = (pos + 64LL * T - 1) / (64LL * T) * (64LL * T);
   vrp[(size_t)vm] = total;
-  if (total > g.total_ub) { std::fprintf(stderr, "libgcnspmm: csr2tile: internal capacity bound violated\n"); std::abort(); }
+  if (total > g.total_ub) { std::fprintf(stderr, "libgcnspmm: csr2tile: internal capacity bound violated; nothing packed\n"); return false; }
   const int nchunks = (int)(total / T);
-  // 3. stream (+ values): zero-row entries everywhere, then the rows; the last position a virtual row owns (for the
+  // 2. stream (+ values): zero-row entries everywhere, then the rows; the last position a virtual row owns (for the
   //    last row of a slice: the end of the slice's padding) carries the row-end bit
   unsigned short* stream = reinterpret_cast<unsigned short*>(segNzCV);
-  float* vs = segNzCV + ((size_t)total * 2 + 15) / 16 * 4;        // (16-byte aligned, in floats)
+  float* vs = segNzCV + g.val_off;
   for (long long i = 0; i < total; ++i) stream[i] = (unsigned short)w;
   if (!value_free) std::memset(vs, 0, sizeof(float) * (size_t)total);
   {
@@ -231,7 +255,7 @@ void dropin_pack_group(const int* rowPtr, const int* colIdx, const float* vals, 
     }
   }
   // (vrp[vr+1] of a slice's last row is the next slice's start, i.e. already behind this slice's padding)
-  // 4. chunk metadata and the list of cut rows
+  // 3. chunk metadata and the list of cut rows
   int* meta = seg_rowPtr + 16;
   size_t vr = 0;
   std::vector<int> chunk_row((size_t)nchunks);
@@ -242,7 +266,8 @@ void dropin_pack_group(const int* rowPtr, const int* colIdx, const float* vals, 
     meta[2 * c] = 2 * (int)vr + (vrp[vr] < target ? 1 : 0);
     meta[2 * c + 1] = (int)(vr / (size_t)m) * (w + 1);
   }
-  int* fix = seg_rowPtr + (16 + 2 * (size_t)nchunks + 3) / 4 * 4;
+  for (int* q = meta + 2 * (size_t)nchunks; q < seg_rowPtr + g.fix_off; ++q) *q = 0;
+  int* fix = seg_rowPtr + g.fix_off;
   int nfix = 0;
   for (int c = 1; c < nchunks; ++c) {
     if (!(meta[2 * c] & 1)) continue;
@@ -256,6 +281,23 @@ void dropin_pack_group(const int* rowPtr, const int* colIdx, const float* vals, 
   for (int i = value_free ? n : 0; i < 8 * n_segs; ++i) segVoMap[i] = 0;
   const int header[16] = {kDropinMagic, S, T, w, nchunks, nfix, value_free ? 1 : 0, (int)total, nnz, 0, 0, 0, 0, 0, 0, 0};
   std::memcpy(seg_rowPtr, header, sizeof(header));
+  return true;
+}
+
+// header words as flexspmm expects them for (m, n, n_segs); used on the host (first call) and on the device (every call)
+__host__ __device__ inline bool dropin_header_ok(const int* h, int S, int w, int value_free, int nchunks_ub) {
+  const int nchunks = h[4], nfix = h[5];
+  return h[0] == kDropinMagic && h[1] == S && h[2] == kDropinT && h[3] == w && h[6] == value_free && nchunks > 0 &&
+         nchunks % 64 == 0 && nchunks <= nchunks_ub && (long long)h[7] == (long long)nchunks * kDropinT && nfix >= 0 &&
+         nfix <= nchunks;
+}
+
+// dyn = {buffers recognised, chunk count, cut rows, 0}: what the kernels of this call read instead of host arguments
+__global__ void dropin_guard_kernel(const int* __restrict__ hdr, int S, int w, int value_free, int nchunks_ub,
+                                    int* __restrict__ dyn) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const bool ok = dropin_header_ok(hdr, S, w, value_free, nchunks_ub);
+  dyn[0] = ok ? 1 : 0; dyn[1] = ok ? hdr[4] : 0; dyn[2] = ok ? hdr[5] : 0; dyn[3] = 0;
 }
 }  // namespace
 
@@ -263,27 +305,32 @@ void csr2tile(int* rowPtr, int* colIdx, float* vals, int m, int n, int nnz, int*
               int* segVoMap, int* seg_rowPtr, float* segNzCV, int* grouped_tailSeg, int* next_seg,
               int tm, int* n_segs) {
   (void)vo_mp;
+  if (n_segs) n_segs[0] = 0;                           // (a failure below leaves "nothing packed" behind)
   if (tm != 8) {
-    std::fprintf(stderr, "libgcnspmm: csr2tile: tm must be 8 (got %d)\n", tm);
-    std::abort();
-  }
-  check_csr_or_die("csr2tile", rowPtr, colIdx, m, nnz);
-  const int ns = nnz / 9;
-  const int T = dropin_T(ns);
-  const int nchunks = (int)(((long long)nnz + T - 1) / T);
-  if (m + 1 > 9 * ns || nchunks > 8 * ns) {
-    std::fprintf(stderr, "libgcnspmm: csr2tile: graph too sparse to pack into the caller's "
-                         "buffers (m=%d nnz=%d); need nnz >= m+10\n", m, nnz);
-    std::abort();
-  }
-  DropinGroup gg;
-  if (dropin_group(m, n, ns, &gg)) {                   // the group-kernel format (see above)
-    dropin_pack_group(rowPtr, colIdx, vals, m, n, nnz, gg, segVoMap, seg_rowPtr, segNzCV, ns);
-    for (int i = 0; i < 256; ++i) { grouped_tailSeg[i] = 0; next_seg[i] = 0; }
-    n_segs[0] = ns;
+    std::fprintf(stderr, "libgcnspmm: csr2tile: tm must be 8 (got %d); nothing packed\n", tm);
     return;
   }
-  // everything else: the plain CSR (unsliced kernels)
+  if (!csr_checked("csr2tile", rowPtr, colIdx, m, nnz)) return;
+  SortedCsr sc;
+  sort_rows(rowPtr, colIdx, vals, m, nnz, &sc);
+  std::vector<float> u;
+  const bool value_free = values_factor(rowPtr, sc.col, sc.val, m, n, &u);
+  int ns = nnz / 9;
+  if ((ns & 1) != (value_free ? 1 : 0)) --ns;         // the lowest bit of n_segs tells flexspmm (see the layout above)
+  const int T = dropin_T(ns);
+  const int nchunks = (int)(((long long)nnz + T - 1) / T);
+  if (ns <= 0 || m + 1 > 9 * ns || nchunks > 8 * ns) {
+    std::fprintf(stderr, "libgcnspmm: csr2tile: graph too sparse to pack into the caller's "
+                         "buffers (m=%d nnz=%d); need nnz >= m+19; nothing packed\n", m, nnz);
+    return;
+  }
+  for (int i = 0; i < 256; ++i) { grouped_tailSeg[i] = 0; next_seg[i] = 0; }
+  DropinGroup gg;
+  if (dropin_group(m, n, ns, &gg)) {                   // the group-kernel format (see above)
+    if (dropin_pack_group(rowPtr, sc.col, sc.val, m, n, nnz, gg, value_free, u, segVoMap, seg_rowPtr, segNzCV, ns)) n_segs[0] = ns;
+    return;
+  }
+  // everything else: the plain CSR (unsliced kernels), in the caller's row order
   int* cols = reinterpret_cast<int*>(segNzCV);
   float* vs = segNzCV + nnz;
   const int vm = m;
@@ -299,73 +346,93 @@ void csr2tile(int* rowPtr, int* colIdx, float* vals, int m, int n, int nnz, int*
     segVoMap[c] = (c == 0) ? 0 : r;
   }
   for (int i = nchunks; i < 8 * ns; ++i) segVoMap[i] = 0;
-  for (int i = 0; i < 256; ++i) { grouped_tailSeg[i] = 0; next_seg[i] = 0; }
   n_segs[0] = ns;
 }
 
+// a HIP call of flexspmm failed: say so and give up on this call (C stays as the caller handed it over)
+#define FLEX_TRY(expr, what)                                                                         \
+  do {                                                                                               \
+    const hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess) {                                                                          \
+      std::fprintf(stderr, "libgcnspmm: flexspmm: %s failed: %s; C left untouched or incomplete\n", what, hipGetErrorString(e_)); \
+      return;                                                                                        \
+    }                                                                                                \
+  } while (0)
+
 // flexspmm on the group-kernel format: the kernels of the plan API on the caller's packed buffers
 static void flexspmm_group(const int* seg_rowPtr, const float* segNzCV, const int* segVoMap, int m, int n, int k,
-                           const DropinGroup& g, const float* B, float* C) {
-  int h[16];
-  hipError_t e = hipMemcpy(h, seg_rowPtr, sizeof(h), hipMemcpyDeviceToHost);      // (synchronous: legacy stream)
-  if (e != hipSuccess) die("flexspmm header copy", e);
-  const int nchunks = h[4], nfix = h[5], value_free = h[6];
-  const long long total = h[7];
-  if (h[0] != kDropinMagic || h[1] != g.S || h[2] != kDropinT || h[3] != g.w || nchunks <= 0 || nchunks % 64 != 0 ||
-      total != (long long)nchunks * kDropinT || total > g.total_ub || nfix < 0 || nfix > nchunks) {
-    std::fprintf(stderr, "libgcnspmm: flexspmm: the buffers were not packed by this library's csr2tile "
-                         "for m=%d n=%d (header mismatch)\n", m, n);
-    std::abort();
+                           int n_segs, const DropinGroup& g, const float* B, float* C) {
+  const int value_free = n_segs & 1;
+  std::lock_guard<std::mutex> lk(gcn::g_plan_mu);
+  // First sight of these buffers: read the 64-byte header once (synchronous, legacy stream) so that buffers this
+  // library did not pack are REPORTED; afterwards only the device-side guard looks at it.
+  {
+    static auto* seen = new std::set<std::tuple<const void*, const void*, const void*, int, int, int>>();
+    const auto key = std::make_tuple((const void*)seg_rowPtr, (const void*)segNzCV, (const void*)segVoMap, m, n, n_segs);
+    if (!seen->count(key)) {
+      int h[16];
+      FLEX_TRY(hipMemcpy(h, seg_rowPtr, sizeof(h), hipMemcpyDeviceToHost), "header copy");
+      if (!dropin_header_ok(h, g.S, g.w, value_free, g.nchunks_ub)) {
+        std::fprintf(stderr, "libgcnspmm: flexspmm: the buffers were not packed by this library's csr2tile "
+                             "for m=%d n=%d n_segs=%d (header mismatch); C left untouched\n", m, n, n_segs);
+        return;
+      }
+      if (seen->size() > 4096) seen->clear();
+      seen->insert(key);
+    }
   }
   const int kc = (k + 3) / 4 * 4;                                 // the group kernels compute at a multiple of 4
   const int ldb = kc != k ? (kc + 31) / 32 * 32 : padded_ldb(n, k);
-  std::lock_guard<std::mutex> lk(gcn::g_plan_mu);
+  const long long table_rows = (long long)g.S * ((long long)g.w + 1);
+  if (!gcn::spmm_group_eligible(kc, ldb, table_rows, nullptr, nullptr, nullptr)) {
+    std::fprintf(stderr, "libgcnspmm: flexspmm: feature width %d is beyond what the packed format serves for n=%d; "
+                         "C left untouched\n", k, n);
+    return;
+  }
   gcn_spmm_plan* sp = gcn::scratch_plan(nullptr);
-  if (!sp) die("flexspmm scratch plan", hipErrorOutOfMemory);
+  if (!sp) { std::fprintf(stderr, "libgcnspmm: flexspmm: out of host memory; C left untouched\n"); return; }
   gcn_spmm_plan& scratch = *sp;
-  auto grow_or_die = [](gcn::DevBuf<float>& buf, size_t count, const char* what) {
-    if (buf.grow(count) != hipSuccess) die(what, hipErrorOutOfMemory);
-  };
-  grow_or_die(scratch.ws, 2 * (size_t)nchunks * (size_t)kc, "flexspmm workspace");
-  grow_or_die(scratch.cv, (size_t)g.S * (size_t)m * (size_t)kc, "flexspmm slice buffer");
-  grow_or_die(scratch.bpad, (size_t)g.S * (size_t)(g.w + 1) * (size_t)ldb, "flexspmm feature copy");
-  if (kc != k) grow_or_die(scratch.cpad, (size_t)m * (size_t)kc, "flexspmm padded result");
+  FLEX_TRY(scratch.ws.grow(2 * (size_t)g.nchunks_ub * (size_t)kc), "workspace allocation");
+  FLEX_TRY(scratch.cv.grow((size_t)g.S * (size_t)m * (size_t)kc), "slice buffer allocation");
+  FLEX_TRY(scratch.bpad.grow((size_t)table_rows * (size_t)ldb), "feature copy allocation");
+  FLEX_TRY(scratch.dyn.grow(4), "guard allocation");
+  if (kc != k) FLEX_TRY(scratch.cpad.grow((size_t)m * (size_t)kc), "padded result allocation");
   hipStream_t st = nullptr;                                        // legacy default stream (flexspmm.cu:512)
+  int* dyn = scratch.dyn;
+  dropin_guard_kernel<<<1, 64, 0, st>>>(seg_rowPtr, g.S, g.w, value_free, g.nchunks_ub, dyn);
+  FLEX_TRY(hipGetLastError(), "guard launch");
   const float* u = value_free ? reinterpret_cast<const float*>(segVoMap) : nullptr;
-  e = gcn::launch_scale_rows_sliced(scratch.bpad, B, u, n, k, ldb, g.S, g.w, st);
-  if (e != hipSuccess) die("flexspmm feature copy", e);
+  FLEX_TRY(gcn::launch_scale_rows_sliced(scratch.bpad, B, u, n, k, ldb, g.S, g.w, st), "feature copy");
   gcn::GroupArgs ga;
   ga.stream = reinterpret_cast<const unsigned short*>(segNzCV);
-  ga.vals = value_free ? nullptr : segNzCV + ((size_t)total * 2 + 15) / 16 * 4;
+  ga.vals = value_free ? nullptr : segNzCV + g.val_off;
   ga.chunk_meta = seg_rowPtr + 16;
   ga.Bp = scratch.bpad; ga.Cv = scratch.cv; ga.P = scratch.ws;
-  ga.nchunks = nchunks; ga.T = kDropinT; ga.k = kc; ga.ldb = ldb;
-  ga.table_rows = (long long)g.S * ((long long)g.w + 1);
-  e = gcn::launch_spmm_group(ga, st);
-  if (e != hipSuccess) die("flexspmm launch", e);
-  const int* fix = seg_rowPtr + (16 + 2 * (size_t)nchunks + 3) / 4 * 4;
-  e = gcn::launch_group_fixup(fix, nfix, scratch.ws, scratch.cv, kc, st);
-  if (e != hipSuccess) die("flexspmm fix-up", e);
+  ga.nchunks = g.nchunks_ub; ga.T = kDropinT; ga.k = kc; ga.ldb = ldb;   // (upper bound: sizes the grid; the count is dyn[1])
+  ga.dyn = dyn;
+  ga.table_rows = table_rows;
+  FLEX_TRY(gcn::launch_spmm_group(ga, st), "main kernel launch");
+  FLEX_TRY(gcn::launch_group_fixup(seg_rowPtr + g.fix_off, g.nchunks_ub, scratch.ws, scratch.cv, kc, st, dyn), "fix-up launch");
   float* Cc = kc != k ? scratch.cpad.get() : C;
-  e = gcn::launch_slice_reduce(scratch.cv, Cc, nullptr, 0, m, g.S, kc, st, 0, u, gcn::DropoutSpec{});
-  if (e != hipSuccess) die("flexspmm slice reduction", e);
-  if (kc != k) {
-    e = gcn::launch_unpad_rows(C, scratch.cpad, nullptr, 0, m, k, kc, st);
-    if (e != hipSuccess) die("flexspmm result compaction", e);
-  }
+  FLEX_TRY(gcn::launch_slice_reduce(scratch.cv, Cc, nullptr, 0, m, g.S, kc, st, 0, u, gcn::DropoutSpec{}, dyn), "slice reduction launch");
+  if (kc != k) FLEX_TRY(gcn::launch_unpad_rows(C, scratch.cpad, nullptr, 0, m, k, kc, st, dyn), "result compaction launch");
 }
 
 void flexspmm(int* seg_rowPtr, float* segNzCV, int* segVoMap, int* grouped_tailSeg, int* next_seg,
               int m, int n, int k, int n_segs, float* B, float* C) {
   (void)grouped_tailSeg; (void)next_seg;
   if (m <= 0 || k <= 0) return;
+  if (n_segs <= 0) {
+    std::fprintf(stderr, "libgcnspmm: flexspmm: n_segs=%d: csr2tile packed nothing; C left untouched\n", n_segs);
+    return;
+  }
   const int cu = cu_count_cached();
-  if (cu <= 0) { std::fprintf(stderr, "libgcnspmm: flexspmm: no HIP device\n"); std::abort(); }
+  if (cu <= 0) { std::fprintf(stderr, "libgcnspmm: flexspmm: no HIP device; C left untouched\n"); return; }
   DropinGroup gg;
-  if (dropin_group(m, n, n_segs, &gg)) { flexspmm_group(seg_rowPtr, segNzCV, segVoMap, m, n, k, gg, B, C); return; }
+  if (dropin_group(m, n, n_segs, &gg)) { flexspmm_group(seg_rowPtr, segNzCV, segVoMap, m, n, k, n_segs, gg, B, C); return; }
   const int T = dropin_T(n_segs);
   const int vm = m;                                  // (graphs that qualify for slicing take the group format above)
-  const long long nnz_ub = 9LL * n_segs + 8;
+  const long long nnz_ub = 9LL * n_segs + 17;        // (n_segs is nnz/9 or one less)
   const int nchunks_ub = (int)((nnz_ub + T - 1) / T);
   // odd widths: computed at k' = k rounded up to 4 on row-padded copies, as in gcn_spmm_csr_f32_bias_relu
   const bool odd = k > 16 && k % 4 != 0 && pad_b_enabled() &&
@@ -375,13 +442,10 @@ void flexspmm(int* seg_rowPtr, float* segNzCV, int* segVoMap, int* grouped_tailS
   std::lock_guard<std::mutex> lk(gcn::g_plan_mu);
   // scratch of the legacy default stream on this device (the reference launches there, flexspmm.cu:512)
   gcn_spmm_plan* sp = gcn::scratch_plan(nullptr);
-  if (!sp) die("flexspmm scratch plan", hipErrorOutOfMemory);
+  if (!sp) { std::fprintf(stderr, "libgcnspmm: flexspmm: out of host memory; C left untouched\n"); return; }
   gcn_spmm_plan& scratch = *sp;
-  auto grow_or_die = [](gcn::DevBuf<float>& buf, size_t count, const char* what) {
-    if (buf.grow(count) != hipSuccess) die(what, hipErrorOutOfMemory);
-  };
-  grow_or_die(scratch.ws, 2 * (size_t)(nchunks_ub > 0 ? nchunks_ub : 1) * (size_t)kc, "flexspmm workspace");
-  if (odd) grow_or_die(scratch.cpad, (size_t)m * (size_t)kc, "flexspmm padded result");
+  FLEX_TRY(scratch.ws.grow(2 * (size_t)(nchunks_ub > 0 ? nchunks_ub : 1) * (size_t)kc), "workspace allocation");
+  if (odd) FLEX_TRY(scratch.cpad.grow((size_t)m * (size_t)kc), "padded result allocation");
   gcn::SpmmArgs a;
   a.rowptr = seg_rowPtr;
   a.col = reinterpret_cast<const int*>(segNzCV);
@@ -393,20 +457,14 @@ void flexspmm(int* seg_rowPtr, float* segNzCV, int* segVoMap, int* grouped_tailS
   a.nnz_dev = seg_rowPtr + vm;           // exact nnz lives at the end of the (virtual) row pointer
   a.nchunks_grid = nchunks_ub;
   a.tile_cols = auto_tile_cols(n, kc);
-  hipError_t e;
   if (ldb != k) {                        // rows on whole cache lines (and zero columns up to k')
-    grow_or_die(scratch.bpad, (size_t)n * (size_t)ldb, "flexspmm padded features");
-    e = gcn::launch_pad_rows(scratch.bpad, B, n, k, ldb, (hipStream_t) nullptr);
-    if (e != hipSuccess) die("flexspmm feature padding", e);
+    FLEX_TRY(scratch.bpad.grow((size_t)n * (size_t)ldb), "padded feature allocation");
+    FLEX_TRY(gcn::launch_pad_rows(scratch.bpad, B, n, k, ldb, (hipStream_t) nullptr), "feature padding");
     a.B = scratch.bpad;
     a.ldb = ldb;
   }
-  e = gcn::launch_spmm(a, cu, (hipStream_t) nullptr);                    // legacy default stream
-  if (e != hipSuccess) die("flexspmm launch", e);
-  if (odd) {
-    e = gcn::launch_unpad_rows(C, scratch.cpad, nullptr, 0, m, k, kc, (hipStream_t) nullptr);
-    if (e != hipSuccess) die("flexspmm result compaction", e);
-  }
+  FLEX_TRY(gcn::launch_spmm(a, cu, (hipStream_t) nullptr), "launch");                    // legacy default stream
+  if (odd) FLEX_TRY(gcn::launch_unpad_rows(C, scratch.cpad, nullptr, 0, m, k, kc, (hipStream_t) nullptr), "result compaction");
 }
 
 // ---------------------------------------------------------------------------
@@ -417,24 +475,21 @@ void permutate(float* B, int* voMp, int* labels, int m, int n, int k) {
   if (n <= 0 || k <= 0) return;
   gcn::DevBuf<float> shadow;
   const size_t bytes = sizeof(float) * (size_t)n * (size_t)k;
-  hipError_t e = shadow.alloc((size_t)n * (size_t)k);
-  if (e != hipSuccess) die("permutate hipMalloc", e);
-  e = gcn::launch_gather_rows(shadow, B, voMp, n, k, nullptr);
-  if (e != hipSuccess) die("permutate gather", e);
-  e = hipMemcpyAsync(B, shadow, bytes, hipMemcpyDeviceToDevice, nullptr);
-  if (e != hipSuccess) die("permutate copy-back", e);
-  e = hipStreamSynchronize(nullptr);     // the reference synchronises too (permutate.cu:56)
-  if (e != hipSuccess) die("permutate sync", e);
+  auto failed = [](const char* what, hipError_t e) {
+    if (e != hipSuccess) std::fprintf(stderr, "libgcnspmm: permutate: %s failed: %s; B left as it was or incomplete\n", what, hipGetErrorString(e));
+    return e != hipSuccess;
+  };
+  if (failed("allocation", shadow.alloc((size_t)n * (size_t)k))) return;
+  if (failed("gather", gcn::launch_gather_rows(shadow, B, voMp, n, k, nullptr))) return;
+  if (failed("copy-back", hipMemcpyAsync(B, shadow, bytes, hipMemcpyDeviceToDevice, nullptr))) return;
+  (void)failed("synchronisation", hipStreamSynchronize(nullptr));     // the reference synchronises too (permutate.cu:56)
 }
 
 void cuspmm(float* rowPtr, int* col, float* vals, float* X, float* C, int m, int n, int nnz,
             int dim) {
   const int st = gcn_spmm_csr_f32_oneshot(reinterpret_cast<const int32_t*>(rowPtr), col, vals, X,
                                           C, m, n, nnz, dim, nullptr);
-  if (st != GCN_OK) {
-    std::fprintf(stderr, "libgcnspmm: cuspmm failed: %s\n", gcn_status_string(st));
-    std::abort();
-  }
+  if (st != GCN_OK) std::fprintf(stderr, "libgcnspmm: cuspmm failed: %s; C left untouched or incomplete\n", gcn_status_string(st));
 }
 
 }  // extern "C"

@@ -309,6 +309,10 @@ struct Epilogue {                                      // C = dropout(act(A*B + 
   const float* bias = nullptr;
   int relu = 0;
   gcn::DropoutSpec drop;
+  // pre-laid output (gcn_spmm_csr_f32_prelaid; group kernels only): row r is written to row r + r / gap_w of the
+  // destination and multiplied by outscale[r] — the slice-by-slice, column-scaled layout a following SpMM gathers from
+  const float* outscale = nullptr;
+  int gap_w = 0;
 };
 
 // b_ld: row stride of B in floats when the caller of this function has already re-laid it, 0 = k;
@@ -353,6 +357,7 @@ int spmm_impl(gcn_spmm_plan* p, const int32_t* rowptr, const int32_t* col, const
   if (p->prof.armed()) { const auto pr = p->prof.next(); ev0 = pr.first; ev1 = pr.second; }
   a.blocks_per_cu = p->blocks_per_cu;
   a.gather_width = p->gather_width;
+  a.hub_cols = p->hub_cols;
   gcn::Panels& pn = p->panels;
   if (pn.R > 0 && p->nnz > 0 && k > 32) {
     // A = A_in + A_out: the staged part from LDS (raw sums into C), then the rest accumulated by the
@@ -415,7 +420,7 @@ int spmm_impl(gcn_spmm_plan* p, const int32_t* rowptr, const int32_t* col, const
     if (ev1 && hipEventRecord(ev1, st) != hipSuccess) return GCN_ERR_HIP;
     if (gcn::launch_group_fixup(p->group.fix, p->group.nfix, p->ws, p->cv, k, st) != hipSuccess) return GCN_ERR_HIP;
     return gcn::launch_slice_reduce(p->cv, C, bias, relu, p->m, sl.S, k, st, 0, weighted ? nullptr : p->factors.u_row.get(),
-                                    epi.drop) == hipSuccess ? GCN_OK : GCN_ERR_HIP;
+                                    epi.drop, nullptr, epi.outscale, epi.gap_w) == hipSuccess ? GCN_OK : GCN_ERR_HIP;
   }
   a.rowptr = sl.vrowptr; a.col = sl.vcol; a.val = sl.vval; a.chunk_row = sl.vchunk_row;
   a.C = p->cv; a.m = sl.S * p->m; a.bias = nullptr; a.relu = 0;
@@ -497,6 +502,7 @@ const char* gcn_status_string(int s) {
     case GCN_ERR_NO_DEVICE: return "no HIP device";
     case GCN_ERR_CAPACITY: return "caller buffer too small";
     case GCN_ERR_ALLOC: return "device allocation failed";
+    case GCN_ERR_NOT_FACTORED: return "values do not factor as u_row[r]*u_col[c]";
     default: return "unknown status";
   }
 }
@@ -587,6 +593,36 @@ int gcn_spmm_csr_f32(gcn_spmm_plan_t* p, const int32_t* rowptr, const int32_t* c
   return gcn_spmm_csr_f32_epilogue(p, rowptr, col, val, B, C, nullptr, 0, 0.f, 0, 0, k, stream);
 }
 
+int gcn_spmm_plan_prelaid_layout(const gcn_spmm_plan_t* p, int32_t k, int32_t* slices, int32_t* slice_cols,
+                                 int64_t* table_rows, int32_t* ld) {
+  if (!p || k <= 0 || k % 4 != 0) return GCN_ERR_INVALID_ARG;
+  const int ldb = gcn::padded_ldb(p->n, k);
+  // only the value-free group pass gathers from a scaled, slice-by-slice copy of B
+  if (!valless_pays(p, k, ldb) || !group_launch(p, true, false)) return GCN_ERR_INVALID_ARG;
+  if (slices) *slices = p->slicing.S;
+  if (slice_cols) *slice_cols = p->group.w;
+  if (table_rows) *table_rows = group_table_rows(p);
+  if (ld) *ld = ldb;
+  return GCN_OK;
+}
+
+int gcn_spmm_csr_f32_prelaid(gcn_spmm_plan_t* p, const int32_t* rowptr, const int32_t* col, const float* val,
+                             const float* Bp, float* out, const float* out_scale, int32_t out_gap, int32_t k,
+                             void* stream) {
+  if (!p || k <= 0 || out_gap < 0) return GCN_ERR_INVALID_ARG;
+  if (p->m == 0) return GCN_OK;
+  if (!Bp || !out || !rowptr || !col || !val) return GCN_ERR_INVALID_ARG;
+  int32_t ld = 0;
+  const int rc = gcn_spmm_plan_prelaid_layout(p, k, nullptr, nullptr, nullptr, &ld);
+  if (rc != GCN_OK) return rc;
+  if ((((uintptr_t)Bp | (uintptr_t)out) & 15) != 0) return GCN_ERR_INVALID_ARG;
+  Epilogue epi;
+  epi.outscale = out_scale;
+  epi.gap_w = out_gap;
+  bool dropped = false;
+  return spmm_impl(p, rowptr, col, val, Bp, ld, /*b_scaled=*/true, out, epi, k, (hipStream_t)stream, &dropped);
+}
+
 int gcn_dropout_f32(float* dst, const float* src, int64_t count, float dropout_p, uint64_t seed, uint64_t offset,
                     void* stream) {
   if (count < 0 || !(dropout_p >= 0.f && dropout_p < 1.f)) return GCN_ERR_INVALID_ARG;
@@ -668,7 +704,7 @@ int gcn_spmm_plan_set_value_factors(gcn_spmm_plan_t* p, const int32_t* rowptr, c
   if (gcn::verify_value_factors(rowptr, col, val, u_row, u_col, p->m, &ok, st) != hipSuccess) return GCN_ERR_HIP;
   if (!ok) {                                                        // some entry is not u_row[r]*u_col[c]
     build_sliced_streams(p, st);                                    // (the plan keeps working on its value stream)
-    return GCN_ERR_INVALID_ARG;
+    return GCN_ERR_NOT_FACTORED;
   }
   gcn::Factors f;
   if (f.u_row.alloc((size_t)p->m) != hipSuccess || f.u_col_own.alloc((size_t)p->n) != hipSuccess) return GCN_ERR_ALLOC;
@@ -903,6 +939,10 @@ int gcn_spmm_csr_f32_oneshot(const int32_t* rowptr, const int32_t* col, const fl
   a.nnz_dev = nullptr; a.nchunks_grid = p->nchunks;
   a.tile_cols = gcn::auto_tile_cols(n, k);
   return gcn::launch_spmm(a, cu, (hipStream_t)stream) == hipSuccess ? GCN_OK : GCN_ERR_HIP;
+}
+
+int32_t gcn_spmm_auto_slices(int64_t m, int64_t n, int64_t nnz, int32_t value_free) {
+  return gcn::auto_slices(m, n, nnz, value_free != 0);
 }
 
 int32_t gcn_spmm_group_addressing(int64_t table_rows, int32_t ld_floats) {

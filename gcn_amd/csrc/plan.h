@@ -12,6 +12,7 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <cstdlib>
 #include <mutex>
 #include <utility>
 #include <vector>
@@ -147,9 +148,11 @@ struct gcn_spmm_plan {
   gcn::DevBuf<float> cv;                            // partial outputs [S*m x k], grow-only
   gcn::DevBuf<float> bpad;                          // B re-laid (rows padded to whole lines and/or scaled by u_col), grow-only
   gcn::DevBuf<float> cpad;                          // result with k rounded up to a multiple of 4 (k % 4 != 0), grow-only
+  gcn::DevBuf<int> dyn;                             // drop-in flexspmm: {recognised, chunks, cut rows, 0} of the current call (device)
   gcn::EventPairs prof;
   int tile_cols = 0;                                // 0 = auto
   int gather_width = 0;                             // non-zeros per gather instruction of the 64-column kernel: 0 auto, 1, 4
+  int hub_cols = [] { const char* e = std::getenv("GCN_AMD_HUB_COLS"); return e ? std::atoi(e) : 0; }();   // experiment (spmm_kernels.h)
   int blocks_per_cu = 32;                           // grid size: blocks of 4 waves per CU (oversubscribed on purpose)
   gcn::Slicing slicing;
   bool slices_auto = false;                         // the slice count was chosen by auto_slices (enable_slicing(-1))

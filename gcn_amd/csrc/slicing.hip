@@ -87,12 +87,16 @@ template <int VEC>
 __global__ void __launch_bounds__(256)
 slice_reduce_kernel(const float* __restrict__ Cv, float* __restrict__ C,
                     const float* __restrict__ bias, int relu, int m, int S, int k, int accumulate,
-                    const float* __restrict__ rowscale, DropoutSpec drop) {
+                    const float* __restrict__ rowscale, DropoutSpec drop, const int* __restrict__ guard,
+                    const float* __restrict__ outscale, int gap_w) {
+  if (guard && *guard == 0) return;
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int nw = gridDim.x * 4;
   for (int r = wave; r < m; r += nw) {
-    const float rs = rowscale ? rowscale[r] : 1.f;    // value-free main pass: the row's own factor u[r]
+    const float rs = (rowscale ? rowscale[r] : 1.f);
+    const float os = outscale ? outscale[r] : 1.f;             // the consumer's column factor (pre-laid output, see below)
+    const size_t orow = gap_w > 0 ? (size_t)r + (size_t)(r / gap_w) : (size_t)r;    // value-free main pass: the row's own factor u[r]
     for (int x = lane * VEC; x < k; x += 64 * VEC) {
       float acc[VEC];
 #pragma unroll
@@ -112,7 +116,7 @@ slice_reduce_kernel(const float* __restrict__ Cv, float* __restrict__ C,
         for (int i = 0; i < VEC; ++i) acc[i] *= rs;
       }
       if (accumulate) {                             // C already holds another part of the product
-        const float* o = C + (size_t)r * (size_t)k + x;
+        const float* o = C + orow * (size_t)k + x;
 #pragma unroll
         for (int i = 0; i < VEC; ++i) acc[i] += o[i];
       }
@@ -131,7 +135,11 @@ slice_reduce_kernel(const float* __restrict__ Cv, float* __restrict__ C,
           for (int i = 0; i < VEC; ++i) acc[i] = dropout_apply(drop, idx + i, acc[i]);
         }
       }
-      float* o = C + (size_t)r * (size_t)k + x;
+      if (outscale) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i] *= os;
+      }
+      float* o = C + orow * (size_t)k + x;
       if (VEC == 4) *reinterpret_cast<float4*>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
       else {
 #pragma unroll
@@ -150,7 +158,9 @@ typedef float slice_f32x4 __attribute__((ext_vector_type(4)));
 __global__ void __launch_bounds__(256)
 slice_reduce_wide_kernel(const float* __restrict__ Cv, float* __restrict__ C,
                          const float* __restrict__ bias, int relu, int m, int S, int k, int accumulate,
-                         const float* __restrict__ rowscale, DropoutSpec drop) {
+                         const float* __restrict__ rowscale, DropoutSpec drop, const int* __restrict__ guard,
+                         const float* __restrict__ outscale, int gap_w) {
+  if (guard && *guard == 0) return;
   const int lane = threadIdx.x & 63;
   const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const long long nw = (long long)gridDim.x * 4;
@@ -175,7 +185,10 @@ slice_reduce_wide_kernel(const float* __restrict__ Cv, float* __restrict__ C,
       acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
     if (rowscale) { const float rs = rowscale[r]; acc.x *= rs; acc.y *= rs; acc.z *= rs; acc.w *= rs; }
-    float* o = C + (size_t)r * (size_t)k + x;
+    // pre-laid output (gcn_spmm_csr_f32_prelaid): row r lands in the consumer's slice-by-slice feature layout — one
+    // (all-zero, never written) row behind every gap_w rows — already multiplied by the consumer's column factor
+    const size_t orow = gap_w > 0 ? (size_t)r + (size_t)(r / gap_w) : (size_t)r;
+    float* o = C + orow * (size_t)k + x;
     if (accumulate) {                                 // C already holds another part of the product
       const float4 c = *reinterpret_cast<const float4*>(o);
       acc.x += c.x; acc.y += c.y; acc.z += c.z; acc.w += c.w;
@@ -187,6 +200,7 @@ slice_reduce_wide_kernel(const float* __restrict__ Cv, float* __restrict__ C,
     if (relu) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
     if (drop.on())                                    // the dropout mask of the fused epilogue (philox.h)
       acc = dropout_apply4(drop, (unsigned long long)r * (unsigned long long)k + (unsigned long long)x, acc);
+    if (outscale) { const float os = outscale[r]; acc.x *= os; acc.y *= os; acc.z *= os; acc.w *= os; }
     *reinterpret_cast<float4*>(o) = acc;
   }
 }
@@ -246,7 +260,8 @@ hipError_t build_sliced_csr(const int* rowptr, const int* col, const float* val,
 }
 
 hipError_t launch_slice_reduce(const float* Cv, float* C, const float* bias, int relu, int m, int S,
-                               int k, hipStream_t st, int accumulate, const float* rowscale, const DropoutSpec& drop) {
+                               int k, hipStream_t st, int accumulate, const float* rowscale, const DropoutSpec& drop,
+                               const int* guard, const float* outscale, int gap_w) {
   if (m <= 0 || k <= 0) return hipSuccess;
   int nb = (m + 3) / 4;
   if (nb > 8192) nb = 8192;
@@ -254,9 +269,9 @@ hipError_t launch_slice_reduce(const float* Cv, float* C, const float* bias, int
   if (k % 4 == 0 && 256 % k == 0 && (al & 15) == 0) {
     const long long steps = ((long long)m * k + 255) / 256;      // wave steps of 1 KiB
     const int nbw = (int)(steps / 4 + 1 < 16384 ? steps / 4 + 1 : 16384);
-    slice_reduce_wide_kernel<<<nbw, 256, 0, st>>>(Cv, C, bias, relu, m, S, k, accumulate, rowscale, drop);
-  } else if (k % 4 == 0 && (al & 15) == 0) slice_reduce_kernel<4><<<nb, 256, 0, st>>>(Cv, C, bias, relu, m, S, k, accumulate, rowscale, drop);
-  else                              slice_reduce_kernel<1><<<nb, 256, 0, st>>>(Cv, C, bias, relu, m, S, k, accumulate, rowscale, drop);
+    slice_reduce_wide_kernel<<<nbw, 256, 0, st>>>(Cv, C, bias, relu, m, S, k, accumulate, rowscale, drop, guard, outscale, gap_w);
+  } else if (k % 4 == 0 && (al & 15) == 0) slice_reduce_kernel<4><<<nb, 256, 0, st>>>(Cv, C, bias, relu, m, S, k, accumulate, rowscale, drop, guard, outscale, gap_w);
+  else                              slice_reduce_kernel<1><<<nb, 256, 0, st>>>(Cv, C, bias, relu, m, S, k, accumulate, rowscale, drop, guard, outscale, gap_w);
   return hipGetLastError();
 }
 
@@ -405,7 +420,9 @@ __global__ void group_fix_list_kernel(const int2* __restrict__ meta, const int* 
 // Cv[row, :] = tail piece of chunk c-1 + head pieces of chunks c .. c1, in chunk order.  One thread per float4
 // of FOUR list entries (the loads of the four are in flight together: the pass is latency-bound otherwise).
 __global__ void __launch_bounds__(256)
-group_fixup_kernel(const int4* __restrict__ fix, int nfix, const float* __restrict__ P, float* __restrict__ Cv, int k) {
+group_fixup_kernel(const int4* __restrict__ fix, int nfix, const float* __restrict__ P, float* __restrict__ Cv, int k,
+                   const int* __restrict__ dyn) {
+  if (dyn) { if (dyn[0] == 0) return; nfix = dyn[2]; }          // (drop-in flexspmm: the launch was sized from an upper bound)
   const int k4 = k >> 2;
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long e0 = t / k4 * 4;
@@ -432,11 +449,11 @@ group_fixup_kernel(const int4* __restrict__ fix, int nfix, const float* __restri
   }
 }
 
-hipError_t launch_group_fixup(const int* fix, int nfix, const float* P, float* Cv, int k, hipStream_t s) {
+hipError_t launch_group_fixup(const int* fix, int nfix, const float* P, float* Cv, int k, hipStream_t s, const int* dyn) {
   if (nfix <= 0 || k <= 0) return hipSuccess;
   if (k % 4 != 0) return hipErrorInvalidValue;
   const long long threads = ((long long)nfix + 3) / 4 * (k / 4);
-  group_fixup_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, s>>>(reinterpret_cast<const int4*>(fix), nfix, P, Cv, k);
+  group_fixup_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, s>>>(reinterpret_cast<const int4*>(fix), nfix, P, Cv, k, dyn);
   return hipGetLastError();
 }
 

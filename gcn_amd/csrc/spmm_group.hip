@@ -83,7 +83,10 @@ template <int T, int POLICY, bool VALS, bool RING, bool BIG>
 __device__ __forceinline__ void
 group_walk(const unsigned short* __restrict__ stream, const float* __restrict__ vals, const int2* __restrict__ chunk_meta,
            const float* __restrict__ Bp, float* __restrict__ Cv, float* __restrict__ P,
-           int nchunks, int k, int col_tile, int ldb, int stream_nt, int blocks_per_tile) {
+           int nchunks, int k, int col_tile, int ldb, int stream_nt, int blocks_per_tile, const int* __restrict__ dyn) {
+  // dyn (drop-in flexspmm only): {buffers recognised, chunk count} written by dropin_guard_kernel — the grid was
+  // sized from an upper bound of the chunk count, and buffers this library did not pack are not walked at all
+  if (dyn) { if (dyn[0] == 0) return; nchunks = dyn[1]; }
   const int lane = threadIdx.x & 63;
   const int wib  = threadIdx.x >> 6;
   const int g    = lane >> 4;
@@ -222,16 +225,16 @@ template <int T, int POLICY, bool BIG>
 __global__ void __launch_bounds__(256)
 spmm_group_kernel(const unsigned short* __restrict__ stream, const int2* __restrict__ chunk_meta,
                   const float* __restrict__ Bp, float* __restrict__ Cv, float* __restrict__ P,
-                  int nchunks, int k, int col_tile, int ldb, int stream_nt, int blocks_per_tile) {
-  group_walk<T, POLICY, false, false, BIG>(stream, nullptr, chunk_meta, Bp, Cv, P, nchunks, k, col_tile, ldb, stream_nt, blocks_per_tile);
+                  int nchunks, int k, int col_tile, int ldb, int stream_nt, int blocks_per_tile, const int* __restrict__ dyn) {
+  group_walk<T, POLICY, false, false, BIG>(stream, nullptr, chunk_meta, Bp, Cv, P, nchunks, k, col_tile, ldb, stream_nt, blocks_per_tile, dyn);
 }
 
 template <int T, int POLICY, bool BIG>
 __global__ void __launch_bounds__(256)
 spmm_group_ring_kernel(const unsigned short* __restrict__ stream, const int2* __restrict__ chunk_meta,
                        const float* __restrict__ Bp, float* __restrict__ Cv, float* __restrict__ P,
-                       int nchunks, int k, int col_tile, int ldb, int stream_nt, int blocks_per_tile) {
-  group_walk<T, POLICY, false, true, BIG>(stream, nullptr, chunk_meta, Bp, Cv, P, nchunks, k, col_tile, ldb, stream_nt, blocks_per_tile);
+                       int nchunks, int k, int col_tile, int ldb, int stream_nt, int blocks_per_tile, const int* __restrict__ dyn) {
+  group_walk<T, POLICY, false, true, BIG>(stream, nullptr, chunk_meta, Bp, Cv, P, nchunks, k, col_tile, ldb, stream_nt, blocks_per_tile, dyn);
 }
 
 // the same walk for matrices whose values do not factor: one fp32 value per entry beside the 16-bit stream,
@@ -241,8 +244,9 @@ template <int T, int POLICY, bool BIG>
 __global__ void __launch_bounds__(256)
 spmm_group_weighted_kernel(const unsigned short* __restrict__ stream, const float* __restrict__ vals,
                            const int2* __restrict__ chunk_meta, const float* __restrict__ Bp, float* __restrict__ Cv,
-                           float* __restrict__ P, int nchunks, int k, int col_tile, int ldb, int stream_nt, int blocks_per_tile) {
-  group_walk<T, POLICY, true, false, BIG>(stream, vals, chunk_meta, Bp, Cv, P, nchunks, k, col_tile, ldb, stream_nt, blocks_per_tile);
+                           float* __restrict__ P, int nchunks, int k, int col_tile, int ldb, int stream_nt, int blocks_per_tile,
+                           const int* __restrict__ dyn) {
+  group_walk<T, POLICY, true, false, BIG>(stream, vals, chunk_meta, Bp, Cv, P, nchunks, k, col_tile, ldb, stream_nt, blocks_per_tile, dyn);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -264,8 +268,9 @@ template <int T, bool RING, bool VALS, bool BIG>
 __device__ __forceinline__ void
 group8_walk(const unsigned short* __restrict__ stream, const float* __restrict__ vals, const int2* __restrict__ chunk_meta,
             const float* __restrict__ Bp, float* __restrict__ Cv, float* __restrict__ P,
-            int nchunks, int k, int ldb, int stream_nt) {
+            int nchunks, int k, int ldb, int stream_nt, const int* __restrict__ dyn) {
   static_assert(T % 64 == 0, "a chunk is whole runs of 64 entries");
+  if (dyn) { if (dyn[0] == 0) return; nchunks = dyn[1]; }      // (as group_walk)
   const int lane = threadIdx.x & 63;
   const int wib  = threadIdx.x >> 6;
   const int g    = lane >> 3;
@@ -440,8 +445,8 @@ template <int T, bool RING, bool BIG>
 __global__ void __launch_bounds__(256)
 spmm_group8_kernel(const unsigned short* __restrict__ stream, const int2* __restrict__ chunk_meta,
                    const float* __restrict__ Bp, float* __restrict__ Cv, float* __restrict__ P,
-                   int nchunks, int k, int ldb, int stream_nt) {
-  group8_walk<T, RING, false, BIG>(stream, nullptr, chunk_meta, Bp, Cv, P, nchunks, k, ldb, stream_nt);
+                   int nchunks, int k, int ldb, int stream_nt, const int* __restrict__ dyn) {
+  group8_walk<T, RING, false, BIG>(stream, nullptr, chunk_meta, Bp, Cv, P, nchunks, k, ldb, stream_nt, dyn);
 }
 
 // ... and with the values beside the stream (matrices whose values do not factor); no ring: 138 VGPRs without
@@ -449,8 +454,8 @@ template <int T, bool BIG>
 __global__ void __launch_bounds__(256)
 spmm_group8_weighted_kernel(const unsigned short* __restrict__ stream, const float* __restrict__ vals,
                             const int2* __restrict__ chunk_meta, const float* __restrict__ Bp, float* __restrict__ Cv,
-                            float* __restrict__ P, int nchunks, int k, int ldb, int stream_nt) {
-  group8_walk<T, false, true, BIG>(stream, vals, chunk_meta, Bp, Cv, P, nchunks, k, ldb, stream_nt);
+                            float* __restrict__ P, int nchunks, int k, int ldb, int stream_nt, const int* __restrict__ dyn) {
+  group8_walk<T, false, true, BIG>(stream, vals, chunk_meta, Bp, Cv, P, nchunks, k, ldb, stream_nt, dyn);
 }
 
 // 32-bit byte offsets (entry + slice base) * row_bytes reach every row of the sliced copy?  (__umul24: both factors
@@ -483,9 +488,9 @@ hipError_t launch_group8_t(const GroupArgs& a, int ldb, hipStream_t s) {
   const int stream_nt8 = (size_t)a.nchunks * (size_t)a.T * (a.vals ? 6u : 2u) > ((size_t)64 << 20) ? 1 : 0;
   const int nb8 = 8 * ((per_xcd + 31) / 32);
   const int2* meta = reinterpret_cast<const int2*>(a.chunk_meta);
-  if (a.vals)      spmm_group8_weighted_kernel<T, BIG><<<dim3(nb8), dim3(256), 0, s>>>(a.stream, a.vals, meta, a.Bp, a.Cv, a.P, a.nchunks, a.k, ldb, stream_nt8);
-  else if (a.ring) spmm_group8_kernel<T, true, BIG><<<dim3(nb8), dim3(256), 0, s>>>(a.stream, meta, a.Bp, a.Cv, a.P, a.nchunks, a.k, ldb, stream_nt8);
-  else             spmm_group8_kernel<T, false, BIG><<<dim3(nb8), dim3(256), 0, s>>>(a.stream, meta, a.Bp, a.Cv, a.P, a.nchunks, a.k, ldb, stream_nt8);
+  if (a.vals)      spmm_group8_weighted_kernel<T, BIG><<<dim3(nb8), dim3(256), 0, s>>>(a.stream, a.vals, meta, a.Bp, a.Cv, a.P, a.nchunks, a.k, ldb, stream_nt8, a.dyn);
+  else if (a.ring) spmm_group8_kernel<T, true, BIG><<<dim3(nb8), dim3(256), 0, s>>>(a.stream, meta, a.Bp, a.Cv, a.P, a.nchunks, a.k, ldb, stream_nt8, a.dyn);
+  else             spmm_group8_kernel<T, false, BIG><<<dim3(nb8), dim3(256), 0, s>>>(a.stream, meta, a.Bp, a.Cv, a.P, a.nchunks, a.k, ldb, stream_nt8, a.dyn);
   return hipGetLastError();
 }
 
@@ -504,11 +509,11 @@ hipError_t launch_group_tp(const GroupArgs& a, int ldb, hipStream_t s) {
   const int2* meta = reinterpret_cast<const int2*>(a.chunk_meta);
   for (int t = 0; t < tiles; t += tiles_per_launch) {
     if (a.vals)
-      spmm_group_weighted_kernel<T, POLICY, BIG><<<dim3(nblocks), dim3(256), 0, s>>>(a.stream, a.vals, meta, a.Bp, a.Cv, a.P, a.nchunks, a.k, t, ldb, stream_nt, blocks_per_tile);
+      spmm_group_weighted_kernel<T, POLICY, BIG><<<dim3(nblocks), dim3(256), 0, s>>>(a.stream, a.vals, meta, a.Bp, a.Cv, a.P, a.nchunks, a.k, t, ldb, stream_nt, blocks_per_tile, a.dyn);
     else if (a.ring)
-      spmm_group_ring_kernel<T, POLICY, BIG><<<dim3(nblocks), dim3(256), 0, s>>>(a.stream, meta, a.Bp, a.Cv, a.P, a.nchunks, a.k, t, ldb, stream_nt, blocks_per_tile);
+      spmm_group_ring_kernel<T, POLICY, BIG><<<dim3(nblocks), dim3(256), 0, s>>>(a.stream, meta, a.Bp, a.Cv, a.P, a.nchunks, a.k, t, ldb, stream_nt, blocks_per_tile, a.dyn);
     else
-      spmm_group_kernel<T, POLICY, BIG><<<dim3(nblocks), dim3(256), 0, s>>>(a.stream, meta, a.Bp, a.Cv, a.P, a.nchunks, a.k, t, ldb, stream_nt, blocks_per_tile);
+      spmm_group_kernel<T, POLICY, BIG><<<dim3(nblocks), dim3(256), 0, s>>>(a.stream, meta, a.Bp, a.Cv, a.P, a.nchunks, a.k, t, ldb, stream_nt, blocks_per_tile, a.dyn);
   }
   return hipGetLastError();
 }

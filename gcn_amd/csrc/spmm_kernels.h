@@ -35,6 +35,7 @@ struct SpmmArgs {
   int valless = 0;         // 1: ignore val (every entry counts 1): the caller pre-scaled B and post-scales the rows
   int stream_rows = 0;     // 1: finished rows are written with non-temporal stores (partial rows of a sliced pass: read back
                            // only by the slice reduction; spmm_quad_kernel)
+  int hub_cols = 0;        // > 0 (widest tile, no epilogue): columns below it are gathered with ordinary loads, the rest streamed
   int gather_width = 0;    // 64-column tile: non-zeros per gather instruction, 0 auto (4 when eligible), 1, 4
   int blocks_per_cu = 32;  // grid size in 256-thread blocks per CU (1..64).  Up to 8 (4 for the 108-VGPR
                            // quad kernel) are resident; more = later blocks start as earlier ones end, i.e.
@@ -55,7 +56,7 @@ hipError_t launch_pad_rows(float* dst, const float* src, long long rows, int k, 
 bool spmm_will_use_quad(const SpmmArgs& a);
 // dst[r, 0:k] = act(src[r, 0:k] + bias), src row stride ld >= k
 hipError_t launch_unpad_rows(float* dst, const float* src, const float* bias, int relu, long long rows, int k,
-                             int ld, hipStream_t s);
+                             int ld, hipStream_t s, const int* guard = nullptr);   // guard: skip when *guard == 0
 int pick_vec(int k, int tile_cols, const void* B, const void* C, const void* P);
 void describe_main_kernel(const SpmmArgs& a, char* buf, size_t len);
 
@@ -77,6 +78,8 @@ struct GroupArgs {
   float* Cv;                     // partial outputs [S*m x k]
   float* P;                      // partial slab [2*nchunks x k]
   int nchunks, T, k, ldb;        // T = entries per chunk (of ONE 16-lane group), ldb = row stride of Bp (0 = k)
+  const int* dyn = nullptr;      // drop-in flexspmm: device words {buffers recognised, chunk count, cut rows}; nchunks is then an
+                                 // upper bound that sizes the grid (dropin_guard_kernel, api_dropin.cpp)
   long long table_rows = 0;      // rows of Bp, S * (w + 1): decides 32-bit or 64-bit (BIG) slice-base addressing
   int store_policy = 2;          // partial-row stores: 0 plain, 1 sc1 (write-through), 2 nt (streaming)
   int narrow8 = 1;               // k <= 32 on the eight-engine kernel (spmm_group8_kernel) when nchunks % 64 == 0
@@ -99,7 +102,9 @@ hipError_t build_group_stream(const int* vrowptr, const int* vcol, int m, int n,
                               int* nchunks_host, int** fix_out, int* nfix_host, hipStream_t st,
                               const float* vval = nullptr, float** vals_out = nullptr);
 // Cv[row, :] = sum of the row's pieces in the partial slab P, in chunk order, for every row of the list (k % 4 == 0)
-hipError_t launch_group_fixup(const int* fix, int nfix, const float* P, float* Cv, int k, hipStream_t s);
+// dyn (drop-in flexspmm): nfix is an upper bound, the count is dyn[2] and nothing runs when dyn[0] == 0
+hipError_t launch_group_fixup(const int* fix, int nfix, const float* P, float* Cv, int k, hipStream_t s,
+                              const int* dyn = nullptr);
 // dst[(c / w)*(w+1) + c % w, :] = rowscale[c] * src[c, :] (rowscale nullptr: 1; row stride ld >= k, padding columns zero), row w of
 // every slice zero: the layout GroupArgs::Bp describes
 hipError_t launch_scale_rows_sliced(float* dst, const float* src, const float* rowscale, int n, int k, int ld,
@@ -142,7 +147,8 @@ hipError_t build_sliced_csr(const int* rowptr, const int* col, const float* val,
                             int* sorted_out, hipStream_t st);
 hipError_t launch_slice_reduce(const float* Cv, float* C, const float* bias, int relu, int m, int S,
                                int k, hipStream_t st, int accumulate = 0, const float* rowscale = nullptr,
-                               const DropoutSpec& drop = DropoutSpec{});
+                               const DropoutSpec& drop = DropoutSpec{}, const int* guard = nullptr,   // guard: skip when *guard == 0
+                               const float* outscale = nullptr, int gap_w = 0);   // pre-laid output: row r -> r + r / gap_w, times outscale[r]
 // dst[i] = dropout(src[i]) for i < total, mask from the flat index i (dst may be src)
 hipError_t launch_dropout(float* dst, const float* src, long long total, const DropoutSpec& drop, hipStream_t st);
 // values factor as u[r]*u[c]?  u_out[n] (device), *ok_host = 1 when every stored entry matches within 4 ulp

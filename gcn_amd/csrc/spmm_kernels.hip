@@ -64,6 +64,15 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // goes into the instruction's SGPR offset (col * row_bytes, 32-bit) and the lane part into a
 // constant VGPR offset, so a gather costs v_readlane + s_mul + buffer_load and no 64-bit vector
 // address arithmetic (requires n*k*4 < 4 GiB); otherwise flat 64-bit addressing.
+// streaming (non-temporal) form of load_vec: the line is not kept in L2 ahead of normally loaded ones
+template <int VEC>
+__device__ __forceinline__ void load_vec_nt(const float* p, float (&out)[VEC]) {
+  typedef float vnt __attribute__((ext_vector_type(VEC)));
+  const vnt v = __builtin_nontemporal_load(reinterpret_cast<const vnt*>(p));
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) out[i] = v[i];
+}
+
 template <int VEC, bool BUF>
 __device__ __forceinline__ void gather_row(const float* __restrict__ Bl, __amdgpu_buffer_rsrc_t rsrc,
                                            int voff, int cu, size_t k, unsigned row_bytes,
@@ -102,14 +111,18 @@ __global__ void plan_chunk_rows_kernel(const int* __restrict__ rowptr, int m, in
 // ---------------------------------------------------------------------------
 // main kernel
 // ---------------------------------------------------------------------------
-template <int VEC, int U, bool EPI, bool BUF>
+// HUB: columns below hub_cols are "hub" columns (a degree-descending numbering puts the heavy columns first): their
+// feature rows are gathered with ordinary loads and stay in L2, every other row with streaming loads that do not
+// displace them — cache blocking for skewed graphs whose table is far larger than the caches, without slicing.
+template <int VEC, int U, bool EPI, bool BUF, bool HUB = false>
 __global__ void __launch_bounds__(256)
 spmm_chunk_kernel(const int* __restrict__ g_rowptr, const int* __restrict__ g_col,
                   const float* __restrict__ g_val, const float* __restrict__ g_B,
                   float* __restrict__ g_C, float* __restrict__ g_P,
                   const int* __restrict__ g_chunk_row, const float* __restrict__ g_bias,
                   const int* __restrict__ g_nnz_dev,
-                  int relu, int nchunks, int T, int m, int nnz, int kk, int col_tile, int accumulate, int ldb) {
+                  int relu, int nchunks, int T, int m, int nnz, int kk, int col_tile, int accumulate, int ldb,
+                  int hub_cols = 0) {
   // drop-in (flexspmm) mode: the host does not know nnz; it lives in rowptr[m] and
   // the values follow the column indices in one buffer (api.cpp, csr2tile layout)
   if (g_nnz_dev) {
@@ -220,7 +233,12 @@ spmm_chunk_kernel(const int* __restrict__ g_rowptr, const int* __restrict__ g_co
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const int cu = __builtin_amdgcn_readlane(cj, j + u);
-          gather_row<VEC, BUF>(Bl, rsrc, voff, cu, ldB, row_bytes, b[u]);
+          if constexpr (HUB) {
+            if (cu < hub_cols) load_vec<VEC>(Bl + (size_t)cu * ldB, b[u]);
+            else               load_vec_nt<VEC>(Bl + (size_t)cu * ldB, b[u]);
+          } else {
+            gather_row<VEC, BUF>(Bl, rsrc, voff, cu, ldB, row_bytes, b[u]);
+          }
         }
         if (row_end - pos >= U || row_end < 0) {
           // fast path: the current row does not end strictly inside this batch
@@ -362,6 +380,10 @@ static hipError_t launch_main(const SpmmArgs& a, int nblocks, bool epi, hipStrea
   // buffer addressing needs every byte offset into B to fit 32 bits
   const bool buf = VEC == 1 && (unsigned long long)a.n * (unsigned long long)ldb * 4ull < 0xFFFFFFF0ull;
   for (int t = 0; t < tiles; ++t) {
+    if (a.hub_cols > 0 && !epi) {          // hub columns cached, the rest streamed (flat addressing)
+      spmm_chunk_kernel<VEC, U, false, false, true><<<grid, block, 0, s>>>(GCN_MAIN_ARGS, a.hub_cols);
+      continue;
+    }
     if constexpr (VEC == 1) {
       if (buf) {
         if (epi) spmm_chunk_kernel<VEC, U, true, true><<<grid, block, 0, s>>>(GCN_MAIN_ARGS);
@@ -517,7 +539,8 @@ hipError_t launch_pad_rows(float* dst, const float* src, long long rows, int k, 
 // dst[r, 0:k] = act(src[r, 0:k] + bias): the compact result out of a row-padded one (src row stride ld)
 __global__ void __launch_bounds__(256)
 unpad_rows_kernel(float* __restrict__ dst, const float* __restrict__ src, const float* __restrict__ bias,
-                  int relu, long long rows, int k, int ld) {
+                  int relu, long long rows, int k, int ld, const int* __restrict__ guard) {
+  if (guard && *guard == 0) return;
   const long long total = rows * k;
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
@@ -531,11 +554,11 @@ unpad_rows_kernel(float* __restrict__ dst, const float* __restrict__ src, const 
 }
 
 hipError_t launch_unpad_rows(float* dst, const float* src, const float* bias, int relu, long long rows, int k,
-                             int ld, hipStream_t s) {
+                             int ld, hipStream_t s, const int* guard) {
   if (rows <= 0 || k <= 0) return hipSuccess;
   long long nb = (rows * k + 255) / 256;
   if (nb > 65536) nb = 65536;
-  unpad_rows_kernel<<<(int)nb, 256, 0, s>>>(dst, src, bias, relu, rows, k, ld);
+  unpad_rows_kernel<<<(int)nb, 256, 0, s>>>(dst, src, bias, relu, rows, k, ld, guard);
   return hipGetLastError();
 }
 

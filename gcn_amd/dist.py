@@ -17,6 +17,14 @@ of the local block are remapped ONCE (on the device) to the padded numbering
 slot of the buffer and the exchange is done in place.  Summation order inside a row is unchanged by the
 partition, so every row equals the single-GPU result to rounding.
 
+Pre-laid chains (`prelaid`, on by default where the local operator offers it): when the values factor as
+u[r]·u[c] (a normalised adjacency) the sliced kernels gather from B' = diag(u)·H laid out slice by slice with a
+zero row behind every slice (gcn_spmm_plan_prelaid_layout).  A rank's slot is then sized to a whole number q of
+slices (slot = q·w columns, w = ceil(max_rows / q)), the local plan is told exactly world·q slices, and the
+exchange buffer IS B': the local SpMM writes its rows — already multiplied by u for the NEXT layer — into its
+slot of it (gcn_spmm_csr_f32_prelaid), peers' slots arrive by the exchange, and the O(n·k) scaled copy that
+every rank otherwise makes per layer and plane disappears.
+
 Exchange forms (`exchange=`): "all_gather" — one RCCL all-gather per layer (`all_gather_into_tensor` on
 nccl, the list form on gloo; chosen once from the backend, never by catching an error: a rank-local
 failure must not make one rank issue a different collective than its peers); "direct" — every rank sends
@@ -28,6 +36,8 @@ the same buffer with the same bytes.
 import numpy as np
 import torch
 import torch.distributed as dist
+
+from . import _lib
 
 
 def partition_rows(rowptr, world, balance="nnz"):
@@ -63,7 +73,7 @@ class RowShardedAdjacency:
     """
 
     def __init__(self, rowptr, col, val, n, rank, world, make_local, balance="nnz", value_factor=None,
-                 exchange="all_gather"):
+                 exchange="all_gather", prelaid="auto", plane_cols=64):
         """Whole-graph convenience constructor: every rank passes the same CSR (int32 rowptr/col on the
         device); the partition is derived from it and this rank keeps its block."""
         rowptr_h = rowptr.detach().cpu().numpy().astype(np.int64)
@@ -72,22 +82,23 @@ class RowShardedAdjacency:
         e_lo, e_hi = int(rowptr_h[lo]), int(rowptr_h[hi])
         local_rowptr = torch.from_numpy(rowptr_h[lo:hi + 1] - e_lo).to(col.device)
         self._setup(local_rowptr, col[e_lo:e_hi], val[e_lo:e_hi], bounds, rank, world, make_local,
-                    value_factor, int(rowptr_h[-1]), exchange)
+                    value_factor, int(rowptr_h[-1]), exchange, prelaid, plane_cols)
         if int(n) != self.n:
             raise ValueError("n does not match the row pointer")
 
     @classmethod
     def from_row_block(cls, local_rowptr, local_col, local_val, bounds, rank, world, make_local,
-                       value_factor=None, total_nnz=None, exchange="all_gather"):
+                       value_factor=None, total_nnz=None, exchange="all_gather", prelaid="auto", plane_cols=64):
         """A rank from its own row block: `local_rowptr` [rows+1] (starts at 0), `local_col` GLOBAL column
         ids (any integer dtype; int64 for graphs past 2³¹ columns·entries), `local_val` fp32, `bounds`
         [world+1] the first global row of every rank's block (the same on all ranks)."""
         self = cls.__new__(cls)
         self._setup(local_rowptr, local_col, local_val, np.asarray(bounds, dtype=np.int64), rank, world,
-                    make_local, value_factor, total_nnz, exchange)
+                    make_local, value_factor, total_nnz, exchange, prelaid, plane_cols)
         return self
 
-    def _setup(self, local_rowptr, gcol, val, bounds, rank, world, make_local, value_factor, total_nnz, exchange):
+    def _setup(self, local_rowptr, gcol, val, bounds, rank, world, make_local, value_factor, total_nnz, exchange,
+               prelaid="auto", plane_cols=64):
         if exchange not in ("all_gather", "direct"):
             raise ValueError("exchange must be 'all_gather' or 'direct'")
         self.rank, self.world, self.exchange = int(rank), int(world), exchange
@@ -97,8 +108,6 @@ class RowShardedAdjacency:
         self.n = int(self.bounds[-1])
         self.collective = True     # False = compute this rank's block only (single-GPU rehearsal of rank r of W)
         self.max_rows = int(np.diff(self.bounds).max())
-        if self.world * self.max_rows >= 2 ** 31:
-            raise ValueError("padded column space does not fit int32")
         self.row_lo, self.row_hi = int(self.bounds[rank]), int(self.bounds[rank + 1])
         self.rows = self.row_hi - self.row_lo
         device = gcol.device
@@ -107,6 +116,28 @@ class RowShardedAdjacency:
         self.local_nnz = int(gcol.numel())
         if self.local_nnz >= 2 ** 31:
             raise ValueError("a rank's block must hold fewer than 2^31 non-zeros (use more ranks)")
+        # Pre-laid chains: slots of q whole column slices.  Decided HERE, from numbers every rank has (bounds, world,
+        # the global nnz) — every rank must size its slot alike — and only kept if the local operator then really
+        # offers the layout (checked below, again from numbers that are the same on all ranks).
+        self.prelaid, self.slices_per_rank, self.slice_cols = False, 0, 0
+        if prelaid not in ("auto", True, False):
+            raise ValueError("prelaid must be 'auto', True or False")
+        want = prelaid is True or (prelaid == "auto" and value_factor is not None)
+        if want and value_factor is not None and total_nnz:
+            mean_rows = max(1, self.n // self.world)
+            S_auto = int(_lib.load().gcn_spmm_auto_slices(mean_rows, self.world * self.max_rows,
+                                                          max(1, int(total_nnz) // self.world), 1))
+            if S_auto > 1:
+                q = -(-S_auto // self.world)
+                w = -(-self.max_rows // q)
+                if w <= 32767:
+                    self.prelaid, self.slices_per_rank, self.slice_cols = True, q, w
+                    self.max_rows = q * w                 # the slot: q slices of w columns (>= the longest block)
+        if prelaid is True and not self.prelaid:
+            raise _lib.GcnAmdError("prelaid=True: this partition does not take the pre-laid layout (needs value factors, "
+                                   "a graph the sliced kernels pay on, slices of at most 32 767 columns)")
+        if self.world * self.max_rows >= 2 ** 31:
+            raise ValueError("padded column space does not fit int32")
         self.total_nnz = int(total_nnz) if total_nnz is not None else None
         bounds_t = torch.from_numpy(self.bounds).to(device)
         self._bounds_t = bounds_t
@@ -129,6 +160,14 @@ class RowShardedAdjacency:
             u = value_factor.to(device=device, dtype=torch.float32)
             self._factors = (u[self.row_lo:self.row_hi].contiguous(), self.to_padded(u[:, None])[:, 0].contiguous())
         self.local = self._new_local()
+        if self.prelaid:                                   # does the operator serve the layout this slot was cut for?
+            lay = self.local.prelaid_layout(plane_cols) if (self._factors is not None and hasattr(self.local, "prelaid_layout")) else None
+            ok = (lay is not None and lay["slices"] == self.world * self.slices_per_rank and lay["slice_cols"] == self.slice_cols
+                  and lay["ld"] == plane_cols)
+            if not ok:
+                if prelaid is True:
+                    raise _lib.GcnAmdError(f"prelaid=True: the local operator does not offer the layout (got {lay})")
+                self.prelaid = False                       # (the wider slot stays: harmless for the copying path)
 
     # -- global <-> padded numbering (device side) ---------------------------------------------
     def _pad_index(self, device):
@@ -150,6 +189,35 @@ class RowShardedAdjacency:
     def new_buffer(self, k, device, dtype=torch.float32):
         return torch.zeros((self.world * self.max_rows, k), dtype=dtype, device=device)
 
+    # -- the pre-laid layout: B' = diag(u)·H, slice by slice, one zero row behind every slice ---------------------
+    @property
+    def slot_rows(self):
+        """rows of one rank's slot in an exchange buffer (pre-laid: its q slices with their zero rows)"""
+        return self.slices_per_rank * (self.slice_cols + 1) if self.prelaid else self.max_rows
+
+    def new_prelaid_buffer(self, k, device):
+        return torch.zeros((self.world * self.slot_rows, k), dtype=torch.float32, device=device)
+
+    def _prelaid_index(self, device):
+        c = self._pad_index(device)                        # global row -> padded column id
+        return c + c // self.slice_cols                    # ... -> row of B'
+
+    def to_prelaid(self, H):
+        """global [n, k] -> B' [world*q*(w+1), k]: rows scaled by u, in the slices' layout (zero rows stay zero)"""
+        out = self.new_prelaid_buffer(H.shape[1], H.device)
+        u = self._u_global(H.device)
+        out.index_copy_(0, self._prelaid_index(H.device), H * u[:, None])
+        return out
+
+    def from_prelaid(self, Bp):
+        """B' -> global [n, k] (the scaling undone)"""
+        u = self._u_global(Bp.device)
+        return Bp.index_select(0, self._prelaid_index(Bp.device)) / u[:, None]
+
+    def _u_global(self, device):
+        # u of every global vertex, recovered from the padded column factors this shard keeps
+        return self._factors[1].to(device).index_select(0, self._pad_index(device))
+
     # -- the exchange ---------------------------------------------------------------------------
     def collective_form(self, group=None):
         """which operation a layer's exchange issues (decided from the backend, once)"""
@@ -165,7 +233,7 @@ class RowShardedAdjacency:
             for off in range(1, self.world):               # staggered peer order: rank r starts with r+1
                 peer = (self.rank + off) % self.world
                 src = (self.rank - off) % self.world
-                dst_view = out_padded[src * self.max_rows: (src + 1) * self.max_rows]
+                dst_view = out_padded[src * self.slot_rows: (src + 1) * self.slot_rows]
                 ops.append(dist.P2POp(dist.isend, slot, dist.get_global_rank(group, peer) if group is not None else peer,
                                       group=group))
                 ops.append(dist.P2POp(dist.irecv, dst_view, dist.get_global_rank(group, src) if group is not None else src,
@@ -177,7 +245,7 @@ class RowShardedAdjacency:
             return None
         if dist.get_backend(group) == "nccl":
             return dist.all_gather_into_tensor(out_padded, slot, group=group, async_op=async_op)
-        views = [out_padded[p * self.max_rows: (p + 1) * self.max_rows] for p in range(self.world)]
+        views = [out_padded[p * self.slot_rows: (p + 1) * self.slot_rows] for p in range(self.world)]
         return dist.all_gather(views, slot.clone(), group=group, async_op=async_op)
 
     def another_local(self):
@@ -186,12 +254,17 @@ class RowShardedAdjacency:
         return self._new_local()
 
     def _new_local(self):
-        local = self._make_local(*self._local_args)
+        if self.prelaid:                                   # exactly world*q slices: the slices ARE the slots' fractions
+            local = self._make_local(*self._local_args, slices=self.world * self.slices_per_rank)
+        else:
+            local = self._make_local(*self._local_args)
         if self._factors is not None and hasattr(local, "set_value_factors"):
             try:
                 local.set_value_factors(*self._factors)
-            except Exception:                       # the values do not factor that way: keep reading them
-                self._factors = None
+            except _lib.GcnAmdError as e:
+                if e.status != _lib.ERR_NOT_FACTORED:
+                    raise                           # a real failure (HIP error, allocation, bad arguments): not ours to hide
+                self._factors = None                # the values do not factor that way: keep reading them
         return local
 
     def layer_async(self, H_padded, out_padded, group=None, local=None):
@@ -199,19 +272,53 @@ class RowShardedAdjacency:
         the SpMM that fills the slot); returns the Work handle (None for world == 1).  The caller
         waits on it before the next read of out_padded — this is what lets the exchange of one
         column plane overlap the SpMM of the next (PipelinedAggregation)."""
-        slot = out_padded[self.rank * self.max_rows: (self.rank + 1) * self.max_rows]
+        slot = self._slot(out_padded)
         if self.rows:
-            (local or self.local).matmul_raw(H_padded, out=slot[: self.rows])
+            self._local_spmm(local or self.local, H_padded, slot)
         if self.world > 1 and self.collective:
             return self._exchange(out_padded, slot, group, True)
         return None
 
+    def buffer_rows_of_local_rows(self, device):
+        """where this rank's rows live in an exchange buffer (either layout)"""
+        r = torch.arange(self.rows, device=device)
+        if self.prelaid:
+            return self.rank * self.slot_rows + r + r // self.slice_cols
+        return self.rank * self.max_rows + r
+
+    def buffer_rows_of_rank(self, q, device):
+        """... and the rows of rank q's block (the same arithmetic on every rank)"""
+        r = torch.arange(int(self.bounds[q + 1] - self.bounds[q]), device=device)
+        if self.prelaid:
+            return q * self.slot_rows + r + r // self.slice_cols
+        return q * self.max_rows + r
+
+    def as_buffer_operator(self):
+        """(rowptr, col, val) of the map  exchange buffer -> this rank's rows of the next exchange buffer  — what a
+        layer computes, in buffer coordinates, for checking a result against plain arithmetic: the block itself, or for
+        the pre-laid layout the pattern with B' row ids and the values u[r]² (B' in, B' out)."""
+        rp, pcol, val, _shape = self._local_args
+        if not self.prelaid:
+            return rp, pcol, val
+        u = self._factors[0]
+        rows = torch.repeat_interleave(torch.arange(self.rows, device=pcol.device), (rp[1:] - rp[:-1]).long())
+        return rp, pcol + pcol // self.slice_cols, (u * u)[rows]
+
+    def _slot(self, buf):
+        return buf[self.rank * self.slot_rows: (self.rank + 1) * self.slot_rows]
+
+    def _local_spmm(self, local, src, slot):
+        if self.prelaid:        # src IS B'; the result lands in this rank's slot of the next B', scaled for the next layer
+            local.matmul_prelaid(src, slot, out_scale=self._factors[0], out_gap=self.slice_cols)
+        else:
+            local.matmul_raw(src, out=slot[: self.rows])
+
     def layer(self, H_padded, out_padded, group=None):
         """out = Â · H for the whole graph, in the padded layout, on every rank:
         local row-block SpMM into this rank's slot, then one in-place exchange."""
-        slot = out_padded[self.rank * self.max_rows: (self.rank + 1) * self.max_rows]
+        slot = self._slot(out_padded)
         if self.rows:
-            self.local.matmul_raw(H_padded, out=slot[: self.rows])
+            self._local_spmm(self.local, H_padded, slot)
         if self.world > 1 and self.collective:
             self._exchange(out_padded, slot, group, False)
         return out_padded
@@ -232,8 +339,11 @@ class PipelinedAggregation:
     def __init__(self, shard, k, device, plane_cols=64, group=None, streams=None):
         self.shard, self.k, self.group = shard, int(k), group
         self.widths = [min(plane_cols, k - c) for c in range(0, k, plane_cols)]
-        self.src = [shard.new_buffer(w, device) for w in self.widths]
-        self.dst = [shard.new_buffer(w, device) for w in self.widths]
+        if shard.prelaid and any(w != plane_cols for w in self.widths):
+            raise _lib.GcnAmdError("a pre-laid shard was cut for planes of %d columns; k must be a multiple of it" % plane_cols)
+        make = shard.new_prelaid_buffer if shard.prelaid else shard.new_buffer
+        self.src = [make(w, device) for w in self.widths]
+        self.dst = [make(w, device) for w in self.widths]
         self.pending = [None] * len(self.widths)
         # One HIP stream and one operator (plan + workspaces) per plane: the planes' chains
         # (SpMM passes -> fix-up -> slice reduction -> exchange) are independent, so on separate
@@ -254,8 +364,9 @@ class PipelinedAggregation:
     def load(self, H):
         """global [n, k] features → the planes' source buffers"""
         c = 0
+        conv = self.shard.to_prelaid if self.shard.prelaid else self.shard.to_padded
         for p, w in enumerate(self.widths):
-            self.src[p].copy_(self.shard.to_padded(H[:, c:c + w].contiguous()))
+            self.src[p].copy_(conv(H[:, c:c + w].contiguous()))
             c += w
 
     def load_padded_block(self, fill):
@@ -301,10 +412,17 @@ class PipelinedAggregation:
     def result(self):
         """global [n, k] view of the current layer output (waits for outstanding exchanges)"""
         self.finish()
-        return torch.cat([self.shard.from_padded(b) for b in self.src], 1)
+        conv = self.shard.from_prelaid if self.shard.prelaid else self.shard.from_padded
+        return torch.cat([conv(b) for b in self.src], 1)
 
     def local_rows(self):
         """this rank's own rows of the current layer output, [rows, k] (no global matrix involved)"""
         self.finish()
-        lo = self.shard.rank * self.shard.max_rows
-        return torch.cat([b[lo: lo + self.shard.rows] for b in self.src], 1)
+        sh = self.shard
+        if sh.prelaid:
+            r = torch.arange(sh.rows, device=self.src[0].device)
+            idx = sh.rank * sh.slot_rows + r + r // sh.slice_cols
+            u = sh._factors[0].to(self.src[0].device)
+            return torch.cat([b.index_select(0, idx) / u[:, None] for b in self.src], 1)
+        lo = sh.rank * sh.max_rows
+        return torch.cat([b[lo: lo + sh.rows] for b in self.src], 1)

@@ -174,6 +174,54 @@ class CsrAdjacency:
         """main-kernel launches (column passes) one k-wide SpMM issues"""
         return int(_lib.load().gcn_spmm_plan_num_passes(self.plan, int(k)))
 
+    def prelaid_layout(self, k):
+        """The slice-by-slice, column-scaled feature layout B' a k-wide SpMM of this plan gathers from
+        (gcn_spmm_plan_prelaid_layout) → dict(slices, slice_cols, table_rows, ld), or None when this plan does not take
+        the value-free sliced pass for that width (then matmul_raw is the only form)."""
+        S, w, ld = ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int32(0)
+        rows = ctypes.c_int64(0)
+        vp = lambda x: ctypes.cast(ctypes.byref(x), ctypes.c_void_p)
+        st = _lib.load().gcn_spmm_plan_prelaid_layout(self.plan, int(k), vp(S), vp(w), vp(rows), vp(ld))
+        if st != 0:
+            return None
+        return dict(slices=S.value, slice_cols=w.value, table_rows=rows.value, ld=ld.value)
+
+    def to_prelaid(self, dense, u_col):
+        """B' for `dense` [n x k] (torch arithmetic; the first layer of a chain — later layers get theirs from
+        matmul_prelaid): rows scaled by u_col, slice s at rows [s*(w+1), (s+1)*(w+1)), row w of every slice zero."""
+        lay = self.prelaid_layout(int(dense.shape[1]))
+        if lay is None:
+            raise _lib.GcnAmdError("this plan has no pre-laid feature layout for that width")
+        w, k = lay["slice_cols"], int(dense.shape[1])
+        out = torch.zeros((lay["table_rows"], lay["ld"]), dtype=torch.float32, device=dense.device)
+        c = torch.arange(self.n, device=dense.device)
+        out[c + c // w, :k] = dense * u_col.to(dense.device)[:, None]
+        return out
+
+    def matmul_prelaid(self, Bp, out, out_scale=None, out_gap=0):
+        """out[r + r // out_gap] = out_scale[r] * (Â·B)[r] with B handed over as B' (prelaid_layout): no per-call copy
+        of the features, and the result lands in the B' layout of a consumer whose slices hold `out_gap` of these rows
+        each (out_gap = 0: a plain [m x k] result).  gcn_spmm_csr_f32_prelaid."""
+        lay = self.prelaid_layout(int(out.shape[1]))
+        if lay is None or not (Bp.is_cuda and Bp.dtype == torch.float32 and Bp.is_contiguous()
+                               and tuple(Bp.shape) == (lay["table_rows"], lay["ld"])):
+            raise _lib.GcnAmdError("matmul_prelaid: B' must be the contiguous fp32 [table_rows x ld] array of prelaid_layout(k)")
+        k = int(out.shape[1])
+        need = self.m + (self.m - 1) // out_gap if (out_gap and self.m) else self.m
+        if not (out.is_cuda and out.dtype == torch.float32 and out.is_contiguous() and out.shape[0] >= need):
+            raise ValueError("out must be a contiguous fp32 array with room for every (gapped) row")
+        sp = ctypes.c_void_p()
+        if out_scale is not None:
+            if not (out_scale.is_cuda and out_scale.dtype == torch.float32 and out_scale.is_contiguous()
+                    and out_scale.numel() == self.m):
+                raise ValueError("out_scale must be a contiguous fp32 device vector with m entries")
+            sp = _ptr(out_scale)
+        with torch.cuda.device(self.device):
+            st = _lib.load().gcn_spmm_csr_f32_prelaid(self.plan, _ptr(self.rowptr), _ptr(self.col), _ptr(self.val),
+                                                      _ptr(Bp), _ptr(out), sp, int(out_gap), k, _stream_ptr(self.device))
+        _lib.check(st, "gcn_spmm_csr_f32_prelaid")
+        return out
+
     def autotune(self, k=128, reps=3, verbose=False):
         """Measure, don't guess: time a k-wide SpMM with and without XCD column slicing on this matrix
         and keep the faster configuration.  The automatic rule (auto_slices) is derived from unordered

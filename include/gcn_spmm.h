@@ -36,6 +36,7 @@ extern "C" {
 #define GCN_ERR_NO_DEVICE      3
 #define GCN_ERR_CAPACITY       4   /* caller buffer too small for the packed plan */
 #define GCN_ERR_ALLOC          5
+#define GCN_ERR_NOT_FACTORED   6   /* set_value_factors: some stored entry is not u_row[r]*u_col[c]; the plan keeps its value stream */
 
 const char* gcn_status_string(int status);
 /* library version, "major.minor.patch" */
@@ -150,8 +151,8 @@ int32_t gcn_spmm_plan_num_slices(const gcn_spmm_plan_t* plan);
  * (each term carries one more rounding).  gcn_spmm_plan_enable_slicing detects this by itself for SQUARE
  * matrices with a stored diagonal (u = sqrt(diag)); for anything else — e.g. a row block of such a
  * matrix with renumbered columns — hand the factors over here (device arrays [m] and [n], copied).
- * Every entry is checked (4 ulp): GCN_ERR_INVALID_ARG if one does not factor.  (NULL, NULL) forgets the
- * factors.  The matrix arrays must be the ones the plan was created for. */
+ * Every entry is checked (4 ulp): GCN_ERR_NOT_FACTORED if one does not factor (the plan then keeps working on
+ * its value stream; every other status is a real failure).  (NULL, NULL) forgets the factors.  The matrix arrays must be the ones the plan was created for. */
 int gcn_spmm_plan_set_value_factors(gcn_spmm_plan_t* plan, const int32_t* rowptr_dev, const int32_t* col_dev,
                                     const float* val_dev, const float* u_row_dev, const float* u_col_dev,
                                     void* stream);
@@ -190,6 +191,29 @@ int gcn_spmm_profile_end(gcn_spmm_plan_t* plan, float* ms_out, int32_t* count_ou
 int gcn_spmm_csr_f32_oneshot(const int32_t* rowptr_dev, const int32_t* col_dev,
                      const float* val_dev, const float* B_dev, float* C_dev,
                      int32_t m, int32_t n, int32_t nnz, int32_t k, void* stream);
+
+/* Chains of aggregations (H <- A·H per layer: the multi-GPU pipeline, SGC-style models) without the per-call copy
+ * of B.  A sliced plan whose values factor (u_row[r]*u_col[c]) gathers from B' = diag(u_col)·B laid out slice by
+ * slice: slice s (columns [s*w, (s+1)*w)) at rows [s*(w+1), (s+1)*(w+1)) of a [table_rows x ld] array, row w of every
+ * slice all zero.  gcn_spmm_csr_f32 builds that copy at every call (one pass over B, O(n*k) whatever the matrix
+ * holds); `_prelaid_layout` describes it (GCN_ERR_INVALID_ARG when a k-wide SpMM of this plan does not take that
+ * pass: k % 4 != 0, no factors, no slicing, ...), and `_prelaid` multiplies with a B' the caller already holds:
+ *   out[r + r / out_gap, 0:k] = out_scale[r] * (A·B)[r, 0:k]          (out_gap > 0; out_scale NULL = 1)
+ * i.e. the result is written straight INTO the B' layout of a consumer whose slices hold `out_gap` of these rows
+ * each (the zero row behind every slice is never touched) and already carries the consumer's column factor — the
+ * next layer's call needs no copy at all.  out_gap = 0 writes a plain [m x k] result.  The reference has no
+ * counterpart: its flexspmm re-reads B as handed over on every call (flexspmm.cu:499-544). */
+int gcn_spmm_plan_prelaid_layout(const gcn_spmm_plan_t* plan, int32_t k, int32_t* slices, int32_t* slice_cols,
+                                 int64_t* table_rows, int32_t* ld_floats);
+int gcn_spmm_csr_f32_prelaid(gcn_spmm_plan_t* plan, const int32_t* rowptr_dev, const int32_t* col_dev,
+                             const float* val_dev, const float* Bp_dev, float* out_dev, const float* out_scale_dev,
+                             int32_t out_gap, int32_t k, void* stream);
+
+/* The column-slice count gcn_spmm_plan_enable_slicing(-1) would choose for an m x n matrix with nnz entries
+ * (value_free: its values factor, the group kernels run) — host arithmetic; 0 = no slicing.  A caller that must
+ * align its own buffers with the slices (the multi-GPU row shards: slices = whole fractions of a rank's rows) asks
+ * here first and then passes an explicit count. */
+int32_t gcn_spmm_auto_slices(int64_t m, int64_t n, int64_t nnz, int32_t value_free);
 
 /* How the group kernels (csrc/spmm_group.hip) address a slice-by-slice copy of B with `table_rows` rows of
  * `ld_floats` floats: 0 = 32-bit byte offsets (table below 4 GiB and 2^24 rows), 1 = the slice base is added in

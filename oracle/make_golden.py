@@ -14,6 +14,11 @@ Regenerates tests/golden/*.npz from the REFERENCE ITSELF, in the build container
   utils.normalize_adj_tensor, utils.py:78-90,126-135), i.e. outputs of the
   torch.spmm call site the HIP kernel replaces (gcn1.py:53).
 
+* gcn1_train_cora_shaped.npz — the Python reference's own TRAINING loop on the same Cora-shaped problem:
+  pygcn.gcn1.GCN.fit → _train_without_val (gcn1.py:132-217; Adam lr 0.01, weight decay 5e-4, nll_loss on the
+  training rows), dropout 0, fixed seed, 20 epochs: initial weights, the training rows and labels, the loss of
+  every epoch (recorded by wrapping the nll_loss the loop calls) and the final eval-mode log-probabilities.
+
 The fixtures are data (inputs and expected outputs) — no reference source text.
 Usage:  make -C oracle && python oracle/make_golden.py
 """
@@ -186,9 +191,59 @@ def gen_gcn1():
         print("wrote gcn1_%s.npz (n=%d nnz(Â)=%d)" % (name, n, an.values().numel()), flush=True)
 
 
+def gen_gcn1_train(epochs=20):
+    """forward + backward-through-the-op + Adam, composed by the reference itself"""
+    import torch
+    import torch.nn.functional as F
+    sys.path.insert(0, REF)
+    from pygcn.gcn1 import GCN            # noqa: E402
+    g = np.load(os.path.join(OUT, "gcn1_cora_shaped.npz"))
+    n, nfeat, nhid, ncls = int(g["n"]), int(g["nfeat"]), int(g["nhid"]), int(g["ncls"])
+    Ahat = sp.coo_matrix((g["adj_val"], (g["adj_row"], g["adj_col"])), shape=(n, n)).tocsr()
+    raw = Ahat.copy(); raw.data[:] = 1.0; raw.setdiag(0); raw.eliminate_zeros()      # A itself: fit() normalises (gcn1.py:147-151)
+    raw = raw.tocoo()
+    adj_t = torch.sparse_coo_tensor(np.vstack([raw.row, raw.col]).astype(np.int64), torch.ones(raw.nnz), (n, n)).coalesce()
+    X = torch.sparse_coo_tensor(np.vstack([g["x_row"], g["x_col"]]).astype(np.int64), torch.from_numpy(g["x_val"]),
+                                (n, nfeat)).coalesce()
+    rng = np.random.default_rng(42)
+    # labels a 1-layer GCN can explain (argmax of Â·X·W for a random W): the loss really falls, the gradients are not noise
+    Xs = sp.coo_matrix((g["x_val"], (g["x_row"], g["x_col"])), shape=(n, nfeat)).tocsr()
+    labels = np.asarray((Ahat @ (Xs @ rng.standard_normal((nfeat, ncls)))).argmax(1)).ravel().astype(np.int64)
+    idx_train = np.sort(rng.choice(n, 500, replace=False)).astype(np.int64)
+    torch.manual_seed(15)
+    model = GCN(nfeat=nfeat, nhid=nhid, nclass=ncls, dropout=0.0, lr=0.01, weight_decay=5e-4, device="cpu")
+    init = {k: v.detach().clone().numpy() for k, v in (("w1", model.gc1.weight), ("b1", model.gc1.bias),
+                                                        ("w2", model.gc2.weight), ("b2", model.gc2.bias))}
+    losses = []
+    real_nll = F.nll_loss
+
+    def recording_nll(*a, **kw):                     # the loop's own loss values, epoch by epoch (gcn1.py:184)
+        out = real_nll(*a, **kw)
+        losses.append(float(out.detach()))
+        return out
+    F.nll_loss = recording_nll
+    try:
+        model.fit(X, adj_t, torch.from_numpy(labels), torch.from_numpy(idx_train), train_iters=epochs,
+                  initialize=False, normalize=True)
+    finally:
+        F.nll_loss = real_nll
+    assert len(losses) == epochs and losses[-1] < losses[0]
+    np.savez_compressed(
+        os.path.join(OUT, "gcn1_train_cora_shaped.npz"), epochs=epochs, lr=0.01, weight_decay=5e-4, dropout=0.0,
+        labels=labels, idx_train=idx_train, losses=np.asarray(losses, np.float64),
+        final_out=model.output.detach().numpy(),
+        w1_final=model.gc1.weight.detach().numpy(), b1_final=model.gc1.bias.detach().numpy(),
+        w2_final=model.gc2.weight.detach().numpy(), b2_final=model.gc2.bias.detach().numpy(), **init)
+    print("wrote gcn1_train_cora_shaped.npz: losses %.6f -> %.6f over %d epochs" % (losses[0], losses[-1], epochs), flush=True)
+
+
 if __name__ == "__main__":
+    if "--train-only" in sys.argv:
+        gen_gcn1_train()
+        sys.exit(0)
     if not os.path.isdir(REF):
         sys.exit("needs /root/reference (build container only)")
     os.makedirs(OUT, exist_ok=True)
     gen_reorder()
     gen_gcn1()
+    gen_gcn1_train()

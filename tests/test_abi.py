@@ -117,12 +117,22 @@ def test_csr2tile_packing_respects_caller_capacities():
                                     n, n, nnz, vp(torch.arange(n, dtype=torch.int32)), vp(segVoMap), vp(seg_rowPtr),
                                     vp(segNzCV), vp(tail), vp(nxt), 8, vp(n_segs))
     ns = int(n_segs[0])
-    assert ns == nnz // 9 and 9 * ns >= n + 1
+    # n_segs is nnz/9, or one less so that its lowest bit says "values are u[r]*u[c]" (true for this matrix) — the
+    # only scalar that travels from csr2tile to flexspmm (gcn6.py:353-366 shrinks the buffers by it)
+    assert ns in (nnz // 9, nnz // 9 - 1) and ns % 2 == 1 and 9 * ns >= n + 1
     for t, cap in ((tail, 256), (nxt, 256), (seg_rowPtr, nnz), (segVoMap, nnz), (segNzCV, 2 * nnz)):
         assert bool((t[cap:] == -77).all()), "wrote past the caller's buffer"
     assert np.array_equal(seg_rowPtr[: n + 1].numpy(), rowptr)
     assert np.array_equal(segNzCV[:nnz].numpy().view(np.int32), col)        # exact int32 columns
     assert np.array_equal(segNzCV[nnz:2 * nnz].numpy(), val)
+
+
+def _group_format_offsets(n, n_segs, S):
+    """where the fix list and the values live (api_dropin.cpp dropin_group: pure functions of (m, n, n_segs))"""
+    T = 512
+    total_ub = (9 * n_segs + 17 + S * n + (S + 64) * T + 63) // (64 * T) * (64 * T) + 64 * T
+    nchunks_ub = total_ub // T
+    return (16 + 2 * nchunks_ub + 3) // 4 * 4, (total_ub * 2 + 15) // 16 * 4
 
 
 def _unpack_group_format(seg_rowPtr, segNzCV, segVoMap, n):
@@ -145,7 +155,7 @@ def _unpack_group_format(seg_rowPtr, segNzCV, segVoMap, n):
     if hd["value_free"]:
         u = segVoMap.numpy()[:n].view(np.float32)
     else:
-        voff = (total * 2 + 15) // 16 * 4
+        voff = _group_format_offsets(n, seg_rowPtr.numel() // 9, S)[1]
         vals = segNzCV.numpy()[voff: voff + total][phys][real]
         assert np.all(segNzCV.numpy()[voff: voff + total][phys][~real] == 0)      # padding weighs nothing
     return hd, rows, cols, vals, u, (vrow, ends, real)
@@ -197,7 +207,8 @@ def test_csr2tile_group_format_is_the_matrix():
         assert np.array_equal(meta[:, 0] & 1, began)
         assert np.array_equal(meta[:, 1], (vrow[starts] // n) * (hd["w"] + 1))
         # fix list: exactly the rows that begin in chunk c-1 and run on into chunk c
-        foff = (16 + 2 * hd["nchunks"] + 3) // 4 * 4
+        foff = _group_format_offsets(n, int(n_segs[0]), hd["S"])[0]
+        assert int(n_segs[0]) % 2 == hd["value_free"]                         # the flag flexspmm reads on the host
         fix = seg_rowPtr.numpy()[foff: foff + 4 * hd["nfix"]].reshape(-1, 4)
         cut = np.flatnonzero(began[1:] == 1) + 1
         first_of_row = np.concatenate([[0], np.flatnonzero(ends[:-1] == 1) + 1])              # start entry of every vrow

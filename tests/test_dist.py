@@ -143,3 +143,112 @@ def test_from_row_block_remaps_global_int64_ids_and_refuses_what_cannot_fit():
                                            0, world, make_local)
     with pytest.raises(ValueError):
         RowShardedAdjacency.from_row_block(lrp, gcol, torch.ones(5), bounds, rank, world, make_local, exchange="ring")
+
+
+def test_only_the_values_do_not_factor_status_is_hidden_when_a_shard_builds_its_operator():
+    """RowShardedAdjacency hands its value factors to the local operator; "they do not factor" (GCN_ERR_NOT_FACTORED)
+    means keep the value stream — every other failure of that call must surface (dist.py swallowed all)"""
+    from gcn_amd import _lib
+
+    def local_raising(status, exc=None):
+        class _Local(_OracleLocal):
+            def set_value_factors(self, u_row, u_col):
+                if exc is not None:
+                    raise exc
+                err = _lib.GcnAmdError(f"status {status}")
+                err.status = status
+                raise err
+        return _Local
+
+    rp, ci, va = sym_norm_graph(300, 2000, seed=5)
+    u = torch.ones(300)
+    args = (torch.from_numpy(rp), torch.from_numpy(ci), torch.from_numpy(va), 300, 0, 1)
+    shard = RowShardedAdjacency(*args, local_raising(_lib.ERR_NOT_FACTORED), value_factor=u)
+    assert shard._factors is None                                   # hidden: the shard works on its value stream
+    with pytest.raises(_lib.GcnAmdError):
+        RowShardedAdjacency(*args, local_raising(2), value_factor=u)             # a HIP error is not "does not factor"
+    with pytest.raises(ZeroDivisionError):
+        RowShardedAdjacency(*args, local_raising(0, ZeroDivisionError()), value_factor=u)
+
+
+class _OraclePrelaidLocal(_OracleLocal):
+    """CPU stand-in for a CsrAdjacency that offers the pre-laid feature layout (prelaid_layout / matmul_prelaid /
+    set_value_factors with the semantics of include/gcn_spmm.h), the arithmetic done by the oracle."""
+
+    def __init__(self, rowptr, col, val, shape, slices="auto"):
+        super().__init__(rowptr, col, val, shape)
+        self.S = None if slices == "auto" else int(slices)
+        self.u_row = self.u_col = None
+
+    def set_value_factors(self, u_row, u_col):
+        rows = np.repeat(np.arange(self.shape[0]), np.diff(self.rp))
+        assert np.allclose(u_row.numpy()[rows] * u_col.numpy()[self.ci], self.va, rtol=1e-6)
+        self.u_row, self.u_col = u_row.numpy(), u_col.numpy()
+
+    def prelaid_layout(self, k):
+        if self.S is None or self.u_row is None:
+            return None
+        w = -(-self.shape[1] // self.S)
+        return dict(slices=self.S, slice_cols=w, table_rows=self.S * (w + 1), ld=k)
+
+    def matmul_prelaid(self, Bp, out, out_scale=None, out_gap=0):
+        lay = self.prelaid_layout(out.shape[1])
+        w = lay["slice_cols"]
+        assert tuple(Bp.shape) == (lay["table_rows"], out.shape[1])
+        assert float(Bp[w::w + 1].abs().max()) == 0.0                           # the zero row behind every slice
+        c = np.arange(self.shape[1])
+        ones = np.ones_like(self.va)
+        res = self.u_row[:, None] * oracle_spmm(self.rp, self.ci, ones, Bp.numpy()[c + c // w], fp64=False)
+        if out_scale is not None:
+            res = res * out_scale.numpy()[:, None]
+        r = np.arange(self.shape[0])
+        out[torch.from_numpy(r + r // out_gap if out_gap else r)] = torch.from_numpy(res.astype(np.float32))
+        return out
+
+
+def _prelaid_worker(rank, world, port, q, exchange):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n, k = 17000, 16                                     # 64-column table 4.35 MB > one L2: the plan would slice
+        rp, ci, va = sym_norm_graph(n, 1200000, seed=12)
+        deg = np.diff(rp).astype(np.float64)
+        u = torch.from_numpy(np.sqrt((deg ** -0.5 * deg ** -0.5).astype(np.float32)))   # as graphgen.value_factor_from_degrees
+        H = torch.from_numpy(np.random.default_rng(1).standard_normal((n, k)).astype(np.float32))
+        shard = RowShardedAdjacency(torch.from_numpy(rp), torch.from_numpy(ci), torch.from_numpy(va), n, rank, world,
+                                    _OraclePrelaidLocal, value_factor=u, exchange=exchange, plane_cols=8)
+        qq, w = shard.slices_per_rank, shard.slice_cols
+        ok = shard.prelaid and qq >= 1 and shard.max_rows == qq * w and shard.slot_rows == qq * (w + 1)
+        ok = ok and shard.local.S == world * qq                               # the plan is told exactly the slots' fractions
+        pipe = PipelinedAggregation(shard, k, "cpu", plane_cols=8)
+        pipe.load(H)
+        ok = ok and np.allclose(pipe.result().numpy(), H.numpy(), rtol=1e-6, atol=1e-7)    # B' -> H round trip
+        for _ in range(2):
+            pipe.step()
+        ref = oracle_spmm(rp, ci, va, oracle_spmm(rp, ci, va, H.numpy()))
+        got = pipe.result().numpy()
+        err = float(np.abs(got - ref).max() / np.abs(ref).max())
+        lo, hi = shard.row_lo, shard.row_hi
+        ok = ok and err <= 1e-5 and np.array_equal(pipe.local_rows().numpy(), got[lo:hi])
+        for b in pipe.src:                                                    # zero rows survived two layers + exchanges
+            ok = ok and float(b[w::w + 1].abs().max()) == 0.0
+        q.put((rank, bool(ok), err))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("exchange", ["all_gather", "direct"])
+def test_prelaid_chain_exchanges_the_next_layers_input_directly(exchange):
+    """world-2 gloo: slots of whole column slices, the exchange buffer IS the next layer's pre-laid input
+    (diag(u)·H with a zero row behind every slice, written by the local SpMM's epilogue): two layers equal Â²H"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_prelaid_worker, args=(r, 2, port, q, exchange)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res), res

@@ -69,6 +69,30 @@ def test_training_reduces_the_loss_and_timers_report():
     assert model.gc1.timers.c.af.avms() > 0          # HIP-event timer on the SpMM interval
 
 
+@pytest.mark.parametrize("dataset", ["pubmed", "reddit"])       # Â(XW) for layer 2 (as gcn1) / (ÂX)W (gcn6.py:214-218)
+@pytest.mark.parametrize("fused", [False, True])
+def test_training_trajectory_matches_the_python_reference(dataset, fused):
+    """forward + backward THROUGH THE OP + epilogue backward + Adam, composed: the loss of every epoch and the final
+    log-probabilities of pygcn.gcn1.GCN.fit (gcn1.py:132-217; 20 epochs, dropout 0, recorded by
+    oracle/make_golden.py from the reference itself) are reproduced from the same initial weights — to 1e-4
+    relative on the losses and 1e-4 on the outputs, both layer orders, fused and unfused epilogue."""
+    g, n, raw, X = _golden_problem()
+    t = np.load(os.path.join(GOLDEN, "gcn1_train_cora_shaped.npz"))
+    model = gcn_amd.GCN(int(g["nfeat"]), int(g["nhid"]), int(g["ncls"]), dataset=dataset, device="cuda:0", order=None,
+                        dropout=float(t["dropout"]), lr=float(t["lr"]), weight_decay=float(t["weight_decay"]),
+                        fuse_epilogue=fused).to("cuda:0")
+    _load_weights(model, t)                                    # the reference's initial weights (seed 15)
+    losses = model.fit(X, raw, t["labels"], t["idx_train"], train_iters=int(t["epochs"]), initialize=False)
+    ref = t["losses"]
+    assert len(losses) == len(ref)
+    assert float(np.max(np.abs(np.asarray(losses) - ref) / ref)) <= 1e-4, (losses, ref)
+    assert ref[-1] < 0.93 * ref[0]                             # (a trajectory that moves: 2.018 -> 1.857)
+    assert rel_err(model.predict().cpu().numpy(), t["final_out"]) <= 1e-4
+    for name, p in (("w1_final", model.gc1.weight), ("b1_final", model.gc1.bias), ("w2_final", model.gc2.weight),
+                    ("b2_final", model.gc2.bias)):
+        assert rel_err(p.detach().cpu().numpy(), t[name]) <= 1e-3, name
+
+
 def test_layer_order_auto_runs_the_spmm_at_the_narrower_width_with_the_same_result():
     """(ÂX)W and Â(XW) are the same function; 'auto' picks the one whose SpMM is narrower (§8f.1)"""
     g, n, raw, X = _golden_problem()

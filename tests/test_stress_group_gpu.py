@@ -95,3 +95,47 @@ def test_group8_kernel_random(seed):
     bias = rng.standard_normal(k).astype(np.float32)
     Ce = adj.matmul_raw(Bd, bias=torch.from_numpy(bias).to(d), relu=True).cpu().numpy()
     assert rel_err(Ce, np.maximum(ref + bias, 0)) <= TOL, (seed, n, S, k, name)
+
+
+def _big_child():
+    """runs in a child process with GCN_AMD_GROUP_BIG=1 (the knob is read once per process): every group kernel in
+    its 64-bit slice-base variant — what tables of 4 GiB and more get — against the fp64 oracle"""
+    d = torch.device("cuda:0")
+    seen = set()
+    for seed in range(12):
+        n, rowptr, col, val, rng = _graph(seed)
+        S = int(rng.choice([2, 3, 5, 8, 13, 16]))
+        weighted = seed % 3 == 2
+        if weighted:
+            val = (val * (1.0 + 0.5 * rng.random(len(val)))).astype(np.float32)
+        adj = gcn_amd.CsrAdjacency(torch.from_numpy(rowptr).to(d), torch.from_numpy(col).to(d), torch.from_numpy(val).to(d),
+                                   (n, n), slices=S)
+        for k in (int(rng.choice([36, 64, 100, 128, 41, 192])), int(rng.choice([12, 16, 20, 24, 32]))):
+            name = adj.main_kernel(k)
+            if name.startswith("gcn::spmm_group"):
+                assert name.endswith("true>"), name                          # the BIG instantiation
+                seen.add(name.split("<")[0])
+            B = rng.standard_normal((n, k)).astype(np.float32)
+            C = adj.matmul_raw(torch.from_numpy(B).to(d))
+            err = rel_err(C.cpu().numpy(), oracle_spmm(rowptr, col, val, B))
+            assert err <= TOL, (seed, n, S, k, name, err)
+    assert {"gcn::spmm_group_ring_kernel", "gcn::spmm_group_weighted_kernel", "gcn::spmm_group8_kernel"} <= seen, seen
+    print("big ok", sorted(seen))
+
+
+def test_group_kernels_with_64_bit_slice_bases():
+    """the BIG variants of the group kernels (slice base added in 64 bits; tables past 4 GiB or 2^24 rows use them,
+    gcn_spmm_group_addressing) forced on small graphs through the development knob, in ONE child process"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GCN_AMD_GROUP_BIG="1", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    out = subprocess.run([sys.executable, os.path.abspath(__file__), "--big-child"], env=env, capture_output=True, text=True,
+                         timeout=600, cwd=os.path.dirname(os.path.abspath(__file__)))
+    assert out.returncode == 0 and "big ok" in out.stdout, out.stdout[-1500:] + out.stderr[-1500:]
+
+
+if __name__ == "__main__":
+    import sys
+    if "--big-child" in sys.argv:
+        _big_child()
