@@ -359,6 +359,13 @@ def main():
     l2_bound = local_adj.num_slices > 1 or n_cols * kp * 4 <= (256 << 20)
     frac_l2 = round(gathered / kavg / L2_PEAK, 4) if kavg > 0 else None
     frac_alg = round(achieved / HBM_PEAK, 4)
+    concurrent = len(pipe.widths) if (sharded and pipe.streams is not None) else 1
+    if concurrent > 1:
+        # the planes' main kernels run side by side on their own streams: a launch's duration includes the share of the
+        # chip the other plane holds, so the fractions are taken over the LAYER (all planes' bytes / step time)
+        layer_s = elapsed / args.steps
+        frac_l2 = round(local_nnz * k * 4 / layer_s / L2_PEAK, 4)
+        frac_alg = round(algorithmic_bytes(local_m, local_nnz, k) / layer_s / HBM_PEAK, 4)
 
     # the same SpMM with the matrix values kept (matrices whose values do not factor as u[r]*u[c] run this pass):
     # a second plan told to forget the factors (API, not an environment switch), a short timed loop of its own
@@ -436,7 +443,9 @@ def main():
                 "frac_hbm_compulsory": round(compulsory / spmm_avg / HBM_PEAK, 4) if spmm_avg > 0 else None,
                 "algorithmic_bytes_per_launch": int(balg),
                 "compulsory_bytes_per_spmm": int(compulsory),
-                "launches_per_spmm": passes, "columns_per_launch": cols_per_launch,
+                "launches_per_spmm": passes, "columns_per_launch": cols_per_launch, "concurrent_planes": concurrent,
+                "frac_note": None if concurrent == 1 else "planes run concurrently: frac / frac_l2 / algorithmic_over_hbm_peak are "
+                             "taken over the whole layer (all planes' bytes / ms_per_step), kernel_ms_avg stays per plane launch",
                 "kernel_ms_avg": round(kavg * 1e3, 4),
                 "spmm_ms_min": round(min(kernel_ms), 4) if kernel_ms else None,
                 "spmms_timed": len(kernel_ms),

@@ -60,9 +60,9 @@ std::vector<u64> rank_by_degree(const std::vector<u64>& deg, bool desc) {
 struct Adj {
   int64_t n = 0;
   std::vector<u64> off;   // cumulative degrees
-  std::vector<u64> nb;    // neighbours
-  const u64* begin(u64 slot) const { return nb.data() + off[slot]; }
-  const u64* end(u64 slot) const { return nb.data() + off[slot + 1]; }
+  std::vector<u32> nb;    // neighbours (32-bit: half the bytes the window slides of Gorder pull through the caches)
+  const u32* begin(u64 slot) const { return nb.data() + off[slot]; }
+  const u32* end(u64 slot) const { return nb.data() + off[slot + 1]; }
   u64 deg(u64 slot) const { return off[slot + 1] - off[slot]; }
 };
 
@@ -88,9 +88,9 @@ Adj build_adj(const Csr& g, const std::vector<u64>& rank, char kind) {
     const u64 ru = rank[u];
     for (int32_t e = g.rowptr[u]; e < g.rowptr[u + 1]; ++e) {
       const u64 rv = rank[g.col[e]];
-      a.nb[a.off[ru] + cnt[ru]++] = rv;
-      if (kind == 'U') a.nb[a.off[rv] + cnt[rv]++] = ru;
-      if (kind == 'B') a.nb[a.off[rv + g.n] + cnt[rv + g.n]++] = ru;
+      a.nb[a.off[ru] + cnt[ru]++] = (u32)rv;
+      if (kind == 'U') a.nb[a.off[rv] + cnt[rv]++] = (u32)ru;
+      if (kind == 'B') a.nb[a.off[rv + g.n] + cnt[rv + g.n]++] = (u32)ru;
     }
   }
   for (int64_t s = 0; s < slots; ++s)
@@ -111,7 +111,7 @@ std::vector<u64> bfs_order(const Adj& a) {
     order.push_back(s);
     while (head < order.size()) {
       const u64 w = order[head++];
-      for (const u64* v = a.begin(w); v != a.end(w); ++v) {
+      for (const u32* v = a.begin(w); v != a.end(w); ++v) {
         if (placed[*v]) continue;
         placed[*v] = 1;
         order.push_back(*v);
@@ -131,38 +131,41 @@ std::vector<u64> bfs_order(const Adj& a) {
 class LazyBuckets {
  public:
   explicit LazyBuckets(u64 n)
-      : huge((u64)std::sqrt((double)n)), none_(n + 2),
-        key_(n, kInf), pend_(n, kInf), prev_(n, n + 2), next_(n, n + 2) {}
+      : huge((u64)std::sqrt((double)n)), none_((u32)(n + 2)), node_(n, Node{kInf, kInf, (u32)(n + 2), (u32)(n + 2)}) {}
 
   static constexpr int kInf = INT_MAX / 2;
   u64 huge;            // hub cut-off, sqrt(n) truncated (unitheap.cu:19)
   size_t live = 0;
   u64 top = 0;
 
+  // the record a lazy_add of vertex v is about to touch: the updates of a window slide hit vertices all over the
+  // graph (one cache miss each at scale 20+), and their order is known many steps ahead
+  void prefetch(u64 v) const { __builtin_prefetch(&node_[v], 1, 1); }
+
   void insert(u64 v, int key) {          // unitheap.cu:23-28
-    key_[v] = key;
-    pend_[v] = -key;
+    node_[v].key = key;
+    node_[v].pend = -key;
     ++live;
   }
 
   // unitheap.cu:30-62 — sorts the indices 0..live-1 (the reference's silent
   // assumption: every inserted vertex has an index below `live`).
   void build() {
-    std::vector<u64> g(live);
-    for (size_t i = 0; i < live; ++i) g[i] = i;
-    std::sort(g.begin(), g.end(), [&](u64 a, u64 b) {
-      return key_[a] > key_[b] || (key_[a] == key_[b] && a < b); });
+    std::vector<u32> g(live);
+    for (size_t i = 0; i < live; ++i) g[i] = (u32)i;
+    std::sort(g.begin(), g.end(), [&](u32 a, u32 b) {
+      return node_[a].key > node_[b].key || (node_[a].key == node_[b].key && a < b); });
     top = g[0];
-    int cur = key_[top];
-    bucket(cur).first = top;
+    int cur = node_[top].key;
+    bucket(cur).first = (u32)top;
     for (size_t i = 0; i < g.size(); ++i) {
-      const u64 v = g[i];
-      prev_[v] = i > 0 ? g[i - 1] : none_;
-      next_[v] = i + 1 < g.size() ? g[i + 1] : none_;
-      if (key_[v] != cur) {
+      const u32 v = g[i];
+      node_[v].prev = i > 0 ? g[i - 1] : none_;
+      node_[v].next = i + 1 < g.size() ? g[i + 1] : none_;
+      if (node_[v].key != cur) {
         bucket(cur).last = g[i - 1];
-        bucket(key_[v]).first = v;
-        cur = key_[v];
+        bucket(node_[v].key).first = v;
+        cur = node_[v].key;
       }
     }
     bucket(cur).last = g.back();
@@ -172,40 +175,42 @@ class LazyBuckets {
     u64 t;
     do {
       t = top;
-      if (pend_[top] < 0) decrease_top();
+      if (node_[top].pend < 0) decrease_top();
     } while (top != t);
     remove(top);
     return t;
   }
 
   void remove(u64 v) {                   // unitheap.cu:152-170
-    pend_[v] = kInf;
-    const u64 p = prev_[v], nx = next_[v];
-    if (p != none_) next_[p] = nx;
-    if (nx != none_) prev_[nx] = p;
-    unbucket(v, nx, p);
+    Node& x = node_[v];
+    x.pend = kInf;
+    const u32 p = x.prev, nx = x.next;
+    if (p != none_) node_[p].next = nx;
+    if (nx != none_) node_[nx].prev = p;
+    unbucket((u32)v, nx, p);
     if (top == v) top = nx;
-    prev_[v] = next_[v] = none_;
+    x.prev = x.next = none_;
     --live;
   }
 
   // returns false on the reference's "negative" abort condition
   bool lazy_add(u64 v, int up) {         // unitheap.cu:177-185
-    if (pend_[v] == kInf) return true;
-    if (pend_[v] == 0 && up > 0) {
-      increment(v);
+    Node& x = node_[v];
+    if (x.pend == kInf) return true;
+    if (x.pend == 0 && up > 0) {
+      increment((u32)v);
     } else {
-      pend_[v] += up;
-      if (-pend_[v] > key_[v]) return false;
+      x.pend += up;
+      if (-x.pend > x.key) return false;
     }
     return true;
   }
 
  private:
-  struct Bucket { u64 first, last; };
-  u64 none_;
-  std::vector<int> key_, pend_;
-  std::vector<u64> prev_, next_;
+  struct Node { int key, pend; u32 prev, next; };   // one 16-byte record per vertex: a lazy update is one cache line
+  struct Bucket { u32 first, last; };
+  u32 none_;
+  std::vector<Node> node_;
   std::vector<Bucket> buckets_;
 
   Bucket& bucket(int key) {
@@ -213,61 +218,63 @@ class LazyBuckets {
     return buckets_[key];
   }
 
-  void unbucket(u64 v, u64 nx, u64 p) {  // unitheap.cu:68-76 (note: the first test
-    Bucket& b = bucket(key_[v]);         // does not look at v itself)
+  void unbucket(u32 v, u32 nx, u32 p) {  // unitheap.cu:68-76 (note: the first test
+    Bucket& b = bucket(node_[v].key);    // does not look at v itself)
     if (b.first == b.last) b.first = b.last = none_;
     else if (v == b.first) b.first = nx;
     else if (v == b.last) b.last = p;
   }
 
   void decrease_top() {                  // unitheap.cu:98-149
-    const u64 nx = next_[top];
+    Node& t = node_[top];
+    const u32 nx = t.next;
     if (nx == none_) return;
-    const int key = key_[top];
-    const int leftover = pend_[top] / 2;
-    const int new_key = key + pend_[top] - leftover;
-    if (new_key >= key_[nx]) return;
-    pend_[top] = leftover;
+    const int key = t.key;
+    const int leftover = t.pend / 2;
+    const int new_key = key + t.pend - leftover;
+    if (new_key >= node_[nx].key) return;
+    t.pend = leftover;
 
-    u64 tail = bucket(key).last;
-    u64 after = next_[tail];
-    while (after != none_ && key_[after] >= new_key) {
-      tail = bucket(key_[after]).last;
-      after = next_[tail];
+    u32 tail = bucket(key).last;
+    u32 after = node_[tail].next;
+    while (after != none_ && node_[after].key >= new_key) {
+      tail = bucket(node_[after].key).last;
+      after = node_[tail].next;
     }
-    prev_[nx] = none_;
-    prev_[top] = tail;
-    next_[top] = after;
-    next_[tail] = top;
-    if (after != none_) prev_[after] = top;
+    node_[nx].prev = none_;
+    t.prev = tail;
+    t.next = after;
+    node_[tail].next = (u32)top;
+    if (after != none_) node_[after].prev = (u32)top;
 
-    unbucket(top, nx, none_);
-    key_[top] = new_key;
+    unbucket((u32)top, nx, none_);
+    t.key = new_key;
     Bucket& nb = bucket(new_key);
-    nb.last = top;
-    if (nb.first == none_) nb.first = top;
+    nb.last = (u32)top;
+    if (nb.first == none_) nb.first = (u32)top;
     top = nx;
   }
 
-  void increment(u64 v) {                // unitheap.cu:187-217
-    const u64 head = bucket(key_[v]).first;
-    const u64 p = prev_[v], nx = next_[v];
+  void increment(u32 v) {                // unitheap.cu:187-217
+    Node& x = node_[v];
+    const u32 head = bucket(x.key).first;
+    const u32 p = x.prev, nx = x.next;
     if (head != v) {
-      next_[p] = nx;
-      if (nx != none_) prev_[nx] = p;
-      const u64 before = prev_[head];
-      prev_[v] = before;
-      next_[v] = head;
-      prev_[head] = v;
-      if (before != none_) next_[before] = v;
+      node_[p].next = nx;
+      if (nx != none_) node_[nx].prev = p;
+      const u32 before = node_[head].prev;
+      x.prev = before;
+      x.next = head;
+      node_[head].prev = v;
+      if (before != none_) node_[before].next = v;
     }
     unbucket(v, nx, p);
-    const int key = ++key_[v];
+    const int key = ++x.key;
     Bucket& b = bucket(key);
     b.last = v;
     if (b.first == none_) {
       b.first = v;
-      if (key > key_[top]) top = v;
+      if (key > node_[top].key) top = v;
     }
   }
 };
@@ -275,21 +282,32 @@ class LazyBuckets {
 // order_gorder.cu:88-143.  `b` holds out-lists in slots [0,n) and in-lists in [n,2n).
 bool slide_window(const Adj& b, LazyBuckets& h, u64 incoming, u64 outgoing) {
   const u64 n = (u64)b.n;
-  const u64* op = b.begin(outgoing + n);
-  const u64* oe = b.end(outgoing + n);
-  const u64* np = b.begin(incoming + n);
-  const u64* ne = b.end(incoming + n);
+  const u32* op = b.begin(outgoing + n);
+  const u32* oe = b.end(outgoing + n);
+  const u32* np = b.begin(incoming + n);
+  const u32* ne = b.end(incoming + n);
   bool ok = true;
+  // The updates of one slide hit heap records all over the graph — one cache miss each from scale 20 on — in an
+  // order that is known in advance (the adjacency lists): every list is walked with the record `kAhead` entries on
+  // already requested.  Hints only: the sequence of heap operations, and so every tie-break, is unchanged.
+  constexpr int kAhead = 12;
+  auto add_all = [&](const u32* s, const u32* e, u64 skip, int up) {
+    for (const u32* q = s; q != e && q < s + kAhead; ++q) h.prefetch(*q);
+    for (const u32* q = s; q != e; ++q) {
+      if (q + kAhead < e) h.prefetch(q[kAhead]);
+      if (*q != skip) ok &= h.lazy_add(*q, up);
+    }
+  };
 
   if (outgoing == incoming) {
     op = oe;                                        // no vertex leaves the window
   } else if (b.deg(outgoing) <= h.huge) {
-    for (const u64* c = b.begin(outgoing); c != b.end(outgoing); ++c) ok &= h.lazy_add(*c, -1);
+    add_all(b.begin(outgoing), b.end(outgoing), n + 2, -1);
   }
 
   // parents of exactly one of the two vertices (sorted-list symmetric difference),
   // hubs (out-degree > sqrt n) skipped
-  static thread_local std::vector<u64> leaving, entering;       // scratch, reused across the n calls
+  static thread_local std::vector<u32> leaving, entering;       // scratch, reused across the n calls
   leaving.clear();
   entering.clear();
   while (true) {
@@ -307,18 +325,18 @@ bool slide_window(const Adj& b, LazyBuckets& h, u64 incoming, u64 outgoing) {
     else          { if (b.deg(*op) <= h.huge) leaving.push_back(*op);  ++op; }
   }
 
-  for (u64 p : leaving) {
-    ok &= h.lazy_add(p, -1);
-    for (const u64* s = b.begin(p); s != b.end(p); ++s)
-      if (*s != outgoing) ok &= h.lazy_add(*s, -1);
-  }
-  if (b.deg(incoming) <= h.huge)
-    for (const u64* c = b.begin(incoming); c != b.end(incoming); ++c) ok &= h.lazy_add(*c, +1);
-  for (u64 p : entering) {
-    ok &= h.lazy_add(p, +1);
-    for (const u64* s = b.begin(p); s != b.end(p); ++s)
-      if (*s != incoming) ok &= h.lazy_add(*s, +1);
-  }
+  // (the next parent's list itself is requested while the current one is walked)
+  auto walk = [&](const std::vector<u32>& parents, u64 skip, int up) {
+    for (size_t i = 0; i < parents.size(); ++i) {
+      const u32 p = parents[i];
+      if (i + 1 < parents.size()) { __builtin_prefetch(b.begin(parents[i + 1])); h.prefetch(parents[i + 1]); }
+      ok &= h.lazy_add(p, up);
+      add_all(b.begin(p), b.end(p), skip, up);
+    }
+  };
+  walk(leaving, outgoing, -1);
+  if (b.deg(incoming) <= h.huge) add_all(b.begin(incoming), b.end(incoming), n + 2, +1);
+  walk(entering, incoming, +1);
   return ok;
 }
 

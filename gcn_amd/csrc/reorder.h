@@ -9,6 +9,7 @@ namespace gcn {
 namespace reorder {
 
 typedef uint64_t u64;   // the reference's `ul` (tools.cuh:80)
+typedef uint32_t u32;   // vertex ids inside the adjacency copies and the Gorder heap (n < 2^32 - 2)
 
 struct Csr {
   const int32_t* rowptr;   // [n+1]

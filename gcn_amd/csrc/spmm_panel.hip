@@ -140,7 +140,9 @@ panel_split_scatter_kernel(const int* __restrict__ rowptr, const int* __restrict
       const bool in = inwin && slot < 0;              // staged entry of an ordinary panel
       if (inwin && slot >= 0) {                       // dense panel: straight into its MFMA fragment image
         const int i = r - (r / R) * R, kk = c - w0;   // A[i][kk] of the panel -> row block i/32, k-step kk/2, lane (kk&1)*32 + i%32
-        adense[(((size_t)slot * 4 + (i >> 5)) * (PANEL_W / 2) + (kk >> 1)) * 64 + (kk & 1) * 32 + (i & 31)] = v;
+        // (added, not assigned: a row that stores a column twice sums its entries in every other kernel — the tile is
+        //  zero-filled before this pass, plan time only)
+        atomicAdd(&adense[(((size_t)slot * 4 + (i >> 5)) * (PANEL_W / 2) + (kk >> 1)) * 64 + (kk & 1) * 32 + (i & 31)], v);
       }
       const unsigned long long mi = __ballot(in), mo = __ballot(valid && !inwin);
       const int ri = __builtin_amdgcn_mbcnt_hi((unsigned)(mi >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mi, 0));

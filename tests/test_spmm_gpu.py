@@ -580,26 +580,24 @@ def test_prelaid_chain_needs_no_feature_copy_and_writes_the_next_layers_input():
     assert _adj(rowptr, col, val2, n, n).prelaid_layout(64) is None             # values do not factor
     with pytest.raises(gcn_amd.GcnAmdError):
         _adj(rowptr, col, val, n, n).matmul_prelaid(torch.zeros((10, 64), device=d), torch.zeros((n, 64), device=d))
-    # a row block: rows [lo, hi) of the matrix, all columns — factors handed over, output into ITS rows of a full B'
-    lo, hi = 3000, 9000
+    # a row block (the multi-GPU shards): rows [lo, n) of the matrix, all columns, lo on a slice boundary as dist.py
+    # cuts its slots — factors handed over, the output goes into ITS rows of a B' of the whole column space
+    S = 4
+    w = -(-n // S)
+    lo, hi = w, n
     e0, e1 = int(rowptr[lo]), int(rowptr[hi])
-    blk = _adj((rowptr[lo:hi + 1] - e0).astype(np.int32), col[e0:e1], val[e0:e1], hi - lo, n, slices=4)
+    blk = _adj((rowptr[lo:hi + 1] - e0).astype(np.int32), col[e0:e1], val[e0:e1], hi - lo, n, slices=S)
     blk.set_value_factors(u[lo:hi], u)
     lay = blk.prelaid_layout(64)
-    assert lay is not None and lay["slices"] == 4
-    w = lay["slice_cols"]
+    assert lay is not None and lay["slices"] == S and lay["slice_cols"] == w
     H = rng.standard_normal((n, 64)).astype(np.float32)
     Bp = blk.to_prelaid(torch.from_numpy(H).to(d), u)
     nxt = torch.zeros_like(Bp)
-    lo2 = -(-lo // w) * w                                 # a slot that starts at a slice boundary, as dist.py cuts them
-    e0b = int(rowptr[lo2])
-    blk2 = _adj((rowptr[lo2:hi + 1] - e0b).astype(np.int32), col[e0b:e1], val[e0b:e1], hi - lo2, n, slices=4)
-    blk2.set_value_factors(u[lo2:hi], u)
-    blk2.matmul_prelaid(Bp, nxt[lo2 + lo2 // w:], out_scale=u[lo2:hi], out_gap=w)
-    rr = torch.arange(lo2, hi, device=d)
-    got = (nxt[rr + rr // w] / u[lo2:hi, None]).cpu().numpy()
-    assert rel_err(got, oracle_spmm(rowptr, col, val, H)[lo2:hi]) <= TOL
-    assert float(nxt[w::w + 1].abs().max()) == 0.0 and float(nxt[: lo2 + lo2 // w].abs().max()) == 0.0
+    blk.matmul_prelaid(Bp, nxt[lo + lo // w:], out_scale=u[lo:hi], out_gap=w)
+    rr = torch.arange(lo, hi, device=d)
+    got = (nxt[rr + rr // w] / u[lo:hi, None]).cpu().numpy()
+    assert rel_err(got, oracle_spmm(rowptr, col, val, H)[lo:hi]) <= TOL
+    assert float(nxt[w::w + 1].abs().max()) == 0.0 and float(nxt[: lo + lo // w].abs().max()) == 0.0
 
 
 def test_full_size_products_shape_rcm_reordered():

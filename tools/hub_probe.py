@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--tiles", default="256,128,64")
     ap.add_argument("--hubs", default="0,2048,4096,8192,16384")
     ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--split", default="", help="comma list of H: time A = A_hub (columns < H, compact table of H rows) + A_cold "
+                                                "as two SpMMs instead (the policy sweep is skipped)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     if args.graph == "rmat":
@@ -40,6 +42,45 @@ def main():
     H = graphgen.random_features(n, k, seed=2, device=dev)
     out = torch.empty((n, k), device=dev)
     balg = nnz * (8 + 4 * k) + (n + 1) * 4 + n * k * 4
+    def timed(fn):
+        for _ in range(2):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / args.iters
+
+    if args.split:
+        # two plans: the hub columns' entries against a compact table of H feature rows (a few MiB per 64-column tile:
+        # L2-resident, sliced by the plan's own rule when it is not), the rest against the whole table
+        os.environ["GCN_AMD_HUB_COLS"] = "0"
+        full = gcn_amd.CsrAdjacency(rowptr, col, val, (n, n), symmetric=True)
+        t_full = timed(lambda: full.matmul_raw(H, out=out))
+        print(f"full matrix: {t_full:.3f} ms  {full.main_kernel(k)} slices {full.num_slices}", flush=True)
+        del full
+        rows = torch.repeat_interleave(torch.arange(n, device=dev), (rowptr[1:] - rowptr[:-1]).long())
+        for Hc in [int(h) for h in args.split.split(",")]:
+            m_hub = col < Hc
+            parts = {}
+            for name, mask, ncols in (("hub", m_hub, Hc), ("cold", ~m_hub, n)):
+                cnt = torch.bincount(rows[mask], minlength=n)
+                rp = torch.zeros(n + 1, dtype=torch.int32, device=dev)
+                rp[1:] = torch.cumsum(cnt, 0).to(torch.int32)
+                parts[name] = gcn_amd.CsrAdjacency(rp, col[mask], val[mask], (n, ncols))
+                del cnt
+            Hhub = H[:Hc].contiguous()
+            out2 = torch.empty_like(out)
+            t_hub = timed(lambda: parts["hub"].matmul_raw(Hhub, out=out2))
+            t_cold = timed(lambda: parts["cold"].matmul_raw(H, out=out))
+            t_add = timed(lambda: out.add_(out2))
+            share = float(cs[Hc - 1])
+            print(f"H={Hc} share {share:.3f}: hub {t_hub:.3f} ms ({parts['hub'].main_kernel(k)}, slices {parts['hub'].num_slices}) "
+                  f"cold {t_cold:.3f} ms  add {t_add:.3f} ms  sum {t_hub + t_cold + t_add:.3f} vs full {t_full:.3f}", flush=True)
+            del parts, out2, Hhub
+        return
     print("tile hub_cols share_of_nnz spmm_ms algTB/s", flush=True)
     for tile in [int(t) for t in args.tiles.split(",")]:
         for hub in [int(h) for h in args.hubs.split(",")]:
