@@ -118,7 +118,25 @@ def cpu_baseline(rowptr, col, val, n, k, H, graph):
     }
 
 
-def renumber(rowptr, col, val, order, dev):
+def offline_gorder_rank(rowptr, col, scale):
+    """the rank tools/gorder_rmat24.py computed for exactly this graph (checked by hash), or None"""
+    import hashlib
+    import numpy as np
+    meta_f = os.path.join(ROOT, "profiles", f"r03_gorder_rmat{scale}.json")
+    rank_f = os.path.join(ROOT, "artifacts", f"gorder_rmat{scale}_rank.npy")
+    if not (os.path.exists(meta_f) and os.path.exists(rank_f)):
+        return None
+    meta = json.load(open(meta_f))
+    h = hashlib.sha256()
+    h.update(rowptr.cpu().numpy().tobytes())
+    h.update(col.cpu().numpy().tobytes())
+    rank = np.load(rank_f)
+    if h.hexdigest() != meta["graph_sha256"] or hashlib.sha256(rank.tobytes()).hexdigest() != meta["rank_sha256"]:
+        sys.exit("bench.py: artifacts/gorder rank does not belong to this graph (hash mismatch)")
+    return rank, meta
+
+
+def renumber(rowptr, col, val, order, dev, offline=0):
     """the adjacency in the numbering of `order` (device CSR rewrite); → (rowptr, col, val, seconds of the ordering,
     where it ran).  deg / rcm: the library's device versions (bit-identical to order_deg / order_rcm of the host code);
     gorder: the host algorithm (window 3, renumber.cu:176), the only form that exists."""
@@ -130,12 +148,21 @@ def renumber(rowptr, col, val, order, dev):
     elif order == "rcm":
         rank, where = reorder.order_rcm_device(rowptr, col), "device"
     elif order == "gorder":
-        rank = torch.from_numpy(reorder.order_gorder(rowptr.cpu().numpy(), col.cpu().numpy(), 3)).to(dev)
-        where = "host (1 thread)"
+        pre = offline_gorder_rank(rowptr, col, offline) if offline else None
+        if pre is not None:
+            rank, where = torch.from_numpy(pre[0].astype("int64")).to(dev), None
+            off_meta = pre[1]
+        else:
+            rank = torch.from_numpy(reorder.order_gorder(rowptr.cpu().numpy(), col.cpu().numpy(), 3)).to(dev)
+            where = "host (1 thread)"
     else:
         raise ValueError(order)
     torch.cuda.synchronize()
     secs = time.perf_counter() - t0
+    if where is None:                       # loaded: report what the off-line run measured
+        secs = float(off_meta["gorder_host_seconds"])
+        where = (f"host (1 thread), computed off-line by tools/gorder_rmat24.py on {off_meta.get('host_cpu', '?')} "
+                 f"(profiles/r03_gorder_rmat{offline}.json; rank sha256 {off_meta['rank_sha256'][:16]})")
     rp, ci, va, _vomp = reorder.apply_rank_device(rowptr, col, val, rank)
     return rp, ci, va, secs, where
 
@@ -151,6 +178,9 @@ def main():
                     help="single GPU: renumber the graph before the SpMM (config = what BASELINE.json names: RCM for "
                          "products, none otherwise)")
     ap.add_argument("--rmat-scale", type=int, default=24, help="--graph rmat24: log2 of the vertex count (24 = config 5)")
+    ap.add_argument("--graph-device", default="gpu", choices=["gpu", "cpu"],
+                    help="--graph rmat24: generate the graph with the CPU generators (the same integers on every machine; a "
+                         "Gorder rank computed off-line by tools/gorder_rmat24.py is then loaded instead of recomputed)")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the graph (debug only; invalidates the metric)")
     ap.add_argument("--exchange", default="all_gather", choices=["all_gather", "direct"],
                     help="N > 1: one RCCL all-gather per plane and layer, or a grouped send/recv to every peer")
@@ -213,12 +243,16 @@ def main():
     # ---- inputs ------------------------------------------------------------------------------
     rowptr = col = val = None
     if not sharded:
-        if args.graph == "rmat24":
+        if args.graph == "rmat24" and args.graph_device == "cpu":
+            rowptr, col, val, n = (t.to(dev) if torch.is_tensor(t) else t
+                                   for t in graphgen.make_rmat(args.rmat_scale, device="cpu", seed=5))
+        elif args.graph == "rmat24":
             rowptr, col, val, n = graphgen.make_rmat(args.rmat_scale, device=dev, seed=5)
         else:
             rowptr, col, val, n = graphgen.make_graph(args.graph, device=dev, seed=1, scale=args.scale)
         if order != "none":
-            rowptr, col, val, order_secs, order_where = renumber(rowptr, col, val, order, dev)
+            rowptr, col, val, order_secs, order_where = renumber(rowptr, col, val, order, dev,
+                                                                 offline=args.rmat_scale if args.graph_device == "cpu" else 0)
             torch.cuda.empty_cache()
         nnz = int(col.numel())
         H = graphgen.random_features(n, k, seed=2, device=dev)
@@ -392,7 +426,8 @@ def main():
         flops = 2.0 * nnz * k if not sim else 2.0 * local_nnz * k
         ord_txt = {"none": "no reorder", "deg": "degree-descending order (order_deg)", "rcm": "RCM order (order_rcm)",
                    "gorder": "Gorder (RCM then Gorder, window 3)"}[order]
-        gname = f"R-MAT scale {args.rmat_scale} (Graph500 a,b,c,d = .57,.19,.19,.05, edge factor 16)" if args.graph == "rmat24" \
+        gname = (f"R-MAT scale {args.rmat_scale} (Graph500 a,b,c,d = .57,.19,.19,.05, edge factor 16"
+                 + (", CPU generator" if args.graph_device == "cpu" else "") + ")") if args.graph == "rmat24" \
             else f"{args.graph}-shaped R-MAT graph"
         line = {
             "metric": "SpMM GFLOP/s + achieved HBM GB/s, Reddit feat=128, 1/2/4/8 MI355X",

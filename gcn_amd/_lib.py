@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libgcnspmm.so")
+# (GCN_AMD_LIB: load a private copy — long-running host tools that must survive a rebuild of the in-tree library)
+LIB_PATH = os.environ.get("GCN_AMD_LIB") or os.path.join(_HERE, "lib", "libgcnspmm.so")
 DROPIN_DIR = os.path.join(_HERE, "dropin")
 
 
@@ -60,6 +61,8 @@ SIGNATURES = {
     "gcn_order_deg_device": (ctypes.c_int, [_c_p, _c_p, _c_i32, _c_i32, _c_i32, _c_i32, _c_p, _c_p]),
     "gcn_order_rcm_device": (ctypes.c_int, [_c_p, _c_p, _c_i32, _c_i32, _c_p, _c_p, _c_p]),
     "gcn_csr_apply_rank_device": (ctypes.c_int, [_c_p, _c_p, _c_p, _c_p, _c_i32, _c_i32, _c_p, _c_p, _c_p, _c_p, _c_p]),
+    "gcn_order_rabbit_device": (ctypes.c_int, [_c_p, _c_p, _c_i32, _c_i32, _c_p, _c_p, _c_p, _c_p]),
+    "gcn_order_rabbit": (ctypes.c_int, [_c_p, _c_p, _c_i32, _c_i32, _c_p, _c_p]),
     "gcn_order_deg": (ctypes.c_int, [_c_p, _c_p, _c_i32, _c_i32, _c_i32, _c_i32, _c_p]),
     "gcn_order_rcm": (ctypes.c_int, [_c_p, _c_p, _c_i32, _c_i32, _c_i32, _c_p]),
     "gcn_order_gorder": (ctypes.c_int, [_c_p, _c_p, _c_i32, _c_i32, _c_i32, _c_p]),

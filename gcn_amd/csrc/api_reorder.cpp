@@ -72,6 +72,26 @@ int gcn_csr_apply_rank_device(const int32_t* rowptr_dev, const int32_t* col_dev,
   return bad ? GCN_ERR_INVALID_ARG : GCN_OK;
 }
 
+int gcn_order_rabbit_device(const int32_t* rowptr_dev, const int32_t* col_dev, int32_t n, int32_t nnz,
+                            int32_t* rank_out_dev, int32_t* community_out_dev, int64_t* stats_host, void* stream) {
+  if (n < 0 || nnz < 0 || (n > 0 && (!rowptr_dev || !rank_out_dev)) || (nnz > 0 && !col_dev)) return GCN_ERR_INVALID_ARG;
+  long long st4[4] = {0, 0, 0, 0};
+  const hipError_t e = gcn::device_order_rabbit(rowptr_dev, col_dev, n, nnz, rank_out_dev, community_out_dev, st4, (hipStream_t)stream);
+  if (stats_host) for (int i = 0; i < 4; ++i) stats_host[i] = (int64_t)st4[i];
+  return e == hipSuccess ? GCN_OK : (e == hipErrorOutOfMemory ? GCN_ERR_ALLOC : GCN_ERR_HIP);
+}
+
+int gcn_order_rabbit(const int32_t* rowptr, const int32_t* col, int32_t n, int32_t nnz, int32_t* vomp_out,
+                     int32_t* community_out) {
+  if (!vomp_out || !csr_ok(rowptr, col, n, nnz)) return GCN_ERR_INVALID_ARG;
+  gcn::reorder::Csr g{rowptr, col, n, nnz};
+  std::vector<int32_t> comm;
+  const auto vo = gcn::reorder::order_rabbit_vomp(g, false, community_out ? &comm : nullptr);
+  for (int32_t i = 0; i < n; ++i) vomp_out[i] = vo[i];
+  if (community_out) for (int32_t i = 0; i < n; ++i) community_out[i] = comm[i];
+  return GCN_OK;
+}
+
 int gcn_order_gorder(const int32_t* rowptr, const int32_t* col, int32_t n, int32_t nnz,
                      int32_t window, int64_t* rank_out) {
   if (!rank_out || window < 1 || !csr_ok(rowptr, col, n, nnz)) return GCN_ERR_INVALID_ARG;

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <map>
 #include <new>
@@ -75,9 +76,31 @@ bool group_merge_tiles() { static const bool v = env_on("GCN_AMD_GROUP_MERGE_TIL
 bool group8_enabled() { static const bool v = env_on("GCN_AMD_GROUP8"); return v; }   // k <= 32: eight 8-lane row engines per wave
 bool group_weighted_enabled() { static const bool v = env_on("GCN_AMD_GROUP_WEIGHTED"); return v; }   // group kernel for values that do not factor
 bool quad_stream_rows() { static const bool v = env_on("GCN_AMD_QUAD_NT"); return v; }   // sliced pass with values: nt partial-row stores
-int group_chunk() {                                                                     // entries per 16-lane group chunk
-  static const int v = [] { const int t = env_int("GCN_AMD_GROUP_T", 512); return (t == 256 || t == 512 || t == 1024 || t == 2048) ? t : 512; }();
-  return v;
+// Entries per chunk of one 16-lane group.  A block walks 16 chunks and 4 blocks are resident per CU (114 VGPRs), so the
+// chip holds cu*4 blocks per "round".  Large matrices run many rounds and 512 is the measured optimum
+// (profiles/r02zg_chunk_length_slices.log); a matrix of a few rounds — a rank's row block of an 8-way partition: 1.7
+// rounds at 512 — leaves the last round partly empty, so the length is picked from the multiples of 64 in [256, 1024]
+// that fill whole rounds best (ties: the one closest to 512).  GCN_AMD_GROUP_T pins it (development knob).
+int group_chunk(long long entries, int cu) {
+  static const int forced = [] { const int t = env_int("GCN_AMD_GROUP_T", 0); return (t >= 64 && t <= 4096 && t % 64 == 0) ? t : 0; }();
+  if (forced) return forced;
+  if (cu <= 0) cu = 256;
+  const double round = (double)cu * 4.0;
+  if ((double)entries / (16.0 * 512.0) >= 6.0 * round) return 512;
+  double fills[13], top = 0.0;                         // t = 256 + 64*i
+  for (int i = 0; i < 13; ++i) {
+    const double blocks = (double)entries / (16.0 * (256 + 64 * i));
+    const double rounds = std::ceil(blocks / round);
+    fills[i] = rounds > 0 ? blocks / (rounds * round) : 0.0;
+    if (fills[i] > top) top = fills[i];
+  }
+  int best = 512;
+  bool have = false;
+  for (int i = 0; i < 13; ++i) {                       // among the lengths within 2 % of the best fill: the one closest to 512
+    const int t = 256 + 64 * i;
+    if (fills[i] >= top - 0.02 && (!have || std::abs(t - 512) < std::abs(best - 512))) { best = t; have = true; }
+  }
+  return best;
 }
 bool panel_mfma_enabled() { static const bool v = env_on("GCN_AMD_PANEL_MFMA"); return v; }   // dense panels on the matrix cores
 double panel_mfma_density() {                                                              // ... from this window density up
@@ -454,15 +477,16 @@ void build_sliced_streams(gcn_spmm_plan* p, hipStream_t st) {
     unsigned short* stream = nullptr;
     float* vals = nullptr;
     int *chunk_row = nullptr, *chunk_meta = nullptr, *fix = nullptr, nch = 0, nfix = 0;
-    if (gcn::build_group_stream(sl.vrowptr, sl.vcol, p->m, p->n, sl.S, gcn::group_chunk(), p->group.vrowptr, &stream,
+    const int gT = gcn::group_chunk(p->nnz, p->cu_count);
+    if (gcn::build_group_stream(sl.vrowptr, sl.vcol, p->m, p->n, sl.S, gT, p->group.vrowptr, &stream,
                                 &chunk_row, &chunk_meta, &nch, &fix, &nfix, st, value_free ? nullptr : sl.vval.get(),
                                 value_free ? nullptr : &vals) == hipSuccess && nch > 0) {
       p->group.fix.adopt(fix, 4 * (size_t)nfix); p->group.nfix = nfix;
-      p->group.stream.adopt(stream, (size_t)nch * (size_t)gcn::group_chunk());
-      if (vals) p->group.vals.adopt(vals, (size_t)nch * (size_t)gcn::group_chunk());
+      p->group.stream.adopt(stream, (size_t)nch * (size_t)gT);
+      if (vals) p->group.vals.adopt(vals, (size_t)nch * (size_t)gT);
       p->group.chunk_row.adopt(chunk_row, (size_t)nch);
       p->group.chunk_meta.adopt(chunk_meta, 2 * (size_t)nch);
-      p->group.nchunks = nch; p->group.T = gcn::group_chunk(); p->group.w = w;
+      p->group.nchunks = nch; p->group.T = gT; p->group.w = w;
       p->group.chunk_row.reset();                      // (only the builder needed these two: the kernels read
       p->group.vrowptr.reset();                        //  chunk_meta and the fix list)
       return;
@@ -877,17 +901,16 @@ int gcn_spmm_plan_main_kernel(const gcn_spmm_plan_t* p, int32_t k, int32_t epilo
   const char* bigs = big ? "true" : "false";
   if (a.valless && group_pass(p)) {
     if (gcn::group8_enabled() && a.k <= 32 && p->group.nchunks % 64 == 0)
-      snprintf(buf, (size_t)buflen, "gcn::spmm_group8_kernel<%d, %s, %s>", p->group.T, gcn::group_ring() ? "true" : "false", bigs);
+      snprintf(buf, (size_t)buflen, "gcn::spmm_group8_kernel<%s, %s>", gcn::group_ring() ? "true" : "false", bigs);
     else
-      snprintf(buf, (size_t)buflen, "gcn::spmm_group%s_kernel<%d, %d, %s>", gcn::group_ring() ? "_ring" : "", p->group.T,
-               big ? 2 : gcn::group_store(), bigs);
+      snprintf(buf, (size_t)buflen, "gcn::spmm_group%s_kernel<%d, %s>", gcn::group_ring() ? "_ring" : "", big ? 2 : gcn::group_store(), bigs);
     return GCN_OK;
   }
   if (!a.valless && weighted_pass(p, a.k, ld_eff)) {
     if (gcn::group8_enabled() && a.k <= 32 && p->group.nchunks % 64 == 0)
-      snprintf(buf, (size_t)buflen, "gcn::spmm_group8_weighted_kernel<%d, %s>", p->group.T, bigs);
+      snprintf(buf, (size_t)buflen, "gcn::spmm_group8_weighted_kernel<%s>", bigs);
     else
-      snprintf(buf, (size_t)buflen, "gcn::spmm_group_weighted_kernel<%d, %d, %s>", p->group.T, big ? 2 : gcn::group_store(), bigs);
+      snprintf(buf, (size_t)buflen, "gcn::spmm_group_weighted_kernel<%d, %s>", big ? 2 : gcn::group_store(), bigs);
     return GCN_OK;
   }
   gcn::describe_main_kernel(a, buf, (size_t)buflen);

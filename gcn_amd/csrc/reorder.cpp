@@ -514,7 +514,7 @@ class NbrTable {
 };
 
 // renumber.cu:319-520 (opt_iterative = true, hub grouping off, shyness 1).
-std::vector<int32_t> order_rabbit_vomp(const Csr& g, bool verbose) {
+std::vector<int32_t> order_rabbit_vomp(const Csr& g, bool verbose, std::vector<int32_t>* community_out) {
   const int n = (int)g.n;
   struct Vtx {
     NbrTable w;             // neighbour -> merged edge count (unit weights)
@@ -591,6 +591,7 @@ std::vector<int32_t> order_rabbit_vomp(const Csr& g, bool verbose) {
   vomp.reserve(n);
   std::vector<int> st;
   int n_comm = 0;
+  if (community_out) community_out->assign((size_t)n, -1);
   for (int v = 0; v < n; ++v) {
     if (V[v].tree < 0) continue;
     ++n_comm;
@@ -599,7 +600,7 @@ std::vector<int32_t> order_rabbit_vomp(const Csr& g, bool verbose) {
       const int t = st.back();
       st.pop_back();
       if (lch[t] >= 0) { st.push_back(rch[t]); st.push_back(lch[t]); }
-      else vomp.push_back(t);
+      else { vomp.push_back(t); if (community_out) (*community_out)[(size_t)t] = v; }
     }
   }
   if (verbose) std::printf("Rabbit found %d communities, edges %lld\n", n_comm, n_edges);

@@ -29,7 +29,8 @@ std::vector<u64> order_gorder_complete(const Csr& g, u64 window, bool* ok);
 // DFS pre-order over all components, roots in index order, neighbours in stored order
 std::vector<u64> order_dfs(const Csr& g);
 // Rabbit (serial modularity merging); returns vomp[new] = old
-std::vector<int32_t> order_rabbit_vomp(const Csr& g, bool verbose);
+// (community_out, optional: the surviving top-level vertex every vertex ended up under)
+std::vector<int32_t> order_rabbit_vomp(const Csr& g, bool verbose, std::vector<int32_t>* community_out = nullptr);
 
 // CSR rewrite in the new numbering (rows moved, columns relabelled and sorted
 // ascending, values carried along).  rank[old] = new.

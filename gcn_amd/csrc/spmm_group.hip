@@ -79,11 +79,13 @@ __device__ __forceinline__ void store_row_piece(float* dst, const float4& v) {
 // pointer in 64 bits, per lane, and only the offset INSIDE the slice (< 32 768 rows x < 128 KiB) stays in 32 bits —
 // one more vector instruction per gather (add + carry instead of one add).  Without it the 32-bit byte offset
 // (entry + base) * row_bytes would wrap silently.
-template <int T, int POLICY, bool VALS, bool RING, bool BIG>
+template <int POLICY, bool VALS, bool RING, bool BIG>
 __device__ __forceinline__ void
 group_walk(const unsigned short* __restrict__ stream, const float* __restrict__ vals, const int2* __restrict__ chunk_meta,
            const float* __restrict__ Bp, float* __restrict__ Cv, float* __restrict__ P,
-           int nchunks, int k, int col_tile, int ldb, int stream_nt, int blocks_per_tile, const int* __restrict__ dyn) {
+           int nchunks, int T, int k, int col_tile, int ldb, int stream_nt, int blocks_per_tile, const int* __restrict__ dyn) {
+  // T: entries per chunk of ONE group, a multiple of 64 (a chunk is whole runs of four blocks) — a run-time value: the
+  // plan picks it so that the blocks fill whole rounds of the chip on small matrices (pick_group_chunk, api_spmm.cpp)
   // dyn (drop-in flexspmm only): {buffers recognised, chunk count} written by dropin_guard_kernel — the grid was
   // sized from an upper bound of the chunk count, and buffers this library did not pack are not walked at all
   if (dyn) { if (dyn[0] == 0) return; nchunks = dyn[1]; }
@@ -136,7 +138,6 @@ group_walk(const unsigned short* __restrict__ stream, const float* __restrict__ 
 
   // the stream is stored in runs of 64 entries, lane-major (slicing.hip, group_phys): lane f reads its entries of
   // four consecutive blocks with one 8-byte load (16 bytes for the values)
-  static_assert(T % 64 == 0, "a chunk is whole runs of four blocks");
   typedef unsigned int u32x2_g __attribute__((ext_vector_type(2)));
   const u32x2_g* __restrict__ sp = reinterpret_cast<const u32x2_g*>(stream + (size_t)c * T) + f;
   const f32x4* __restrict__ vp = VALS ? reinterpret_cast<const f32x4*>(vals + (size_t)c * T) + f : nullptr;
@@ -221,32 +222,32 @@ group_walk(const unsigned short* __restrict__ stream, const float* __restrict__ 
   }
 }
 
-template <int T, int POLICY, bool BIG>
+template <int POLICY, bool BIG>
 __global__ void __launch_bounds__(256)
 spmm_group_kernel(const unsigned short* __restrict__ stream, const int2* __restrict__ chunk_meta,
                   const float* __restrict__ Bp, float* __restrict__ Cv, float* __restrict__ P,
-                  int nchunks, int k, int col_tile, int ldb, int stream_nt, int blocks_per_tile, const int* __restrict__ dyn) {
-  group_walk<T, POLICY, false, false, BIG>(stream, nullptr, chunk_meta, Bp, Cv, P, nchunks, k, col_tile, ldb, stream_nt, blocks_per_tile, dyn);
+                  int nchunks, int T, int k, int col_tile, int ldb, int stream_nt, int blocks_per_tile, const int* __restrict__ dyn) {
+  group_walk<POLICY, false, false, BIG>(stream, nullptr, chunk_meta, Bp, Cv, P, nchunks, T, k, col_tile, ldb, stream_nt, blocks_per_tile, dyn);
 }
 
-template <int T, int POLICY, bool BIG>
+template <int POLICY, bool BIG>
 __global__ void __launch_bounds__(256)
 spmm_group_ring_kernel(const unsigned short* __restrict__ stream, const int2* __restrict__ chunk_meta,
                        const float* __restrict__ Bp, float* __restrict__ Cv, float* __restrict__ P,
-                       int nchunks, int k, int col_tile, int ldb, int stream_nt, int blocks_per_tile, const int* __restrict__ dyn) {
-  group_walk<T, POLICY, false, true, BIG>(stream, nullptr, chunk_meta, Bp, Cv, P, nchunks, k, col_tile, ldb, stream_nt, blocks_per_tile, dyn);
+                       int nchunks, int T, int k, int col_tile, int ldb, int stream_nt, int blocks_per_tile, const int* __restrict__ dyn) {
+  group_walk<POLICY, false, true, BIG>(stream, nullptr, chunk_meta, Bp, Cv, P, nchunks, T, k, col_tile, ldb, stream_nt, blocks_per_tile, dyn);
 }
 
 // the same walk for matrices whose values do not factor: one fp32 value per entry beside the 16-bit stream,
 // handed from the lane that loaded it to its group by the same DPP broadcast as the address (one more vector
 // instruction and four FMAs instead of two packed adds per step); Bp is then a plain (unscaled) sliced copy of B
-template <int T, int POLICY, bool BIG>
+template <int POLICY, bool BIG>
 __global__ void __launch_bounds__(256)
 spmm_group_weighted_kernel(const unsigned short* __restrict__ stream, const float* __restrict__ vals,
                            const int2* __restrict__ chunk_meta, const float* __restrict__ Bp, float* __restrict__ Cv,
-                           float* __restrict__ P, int nchunks, int k, int col_tile, int ldb, int stream_nt, int blocks_per_tile,
+                           float* __restrict__ P, int nchunks, int T, int k, int col_tile, int ldb, int stream_nt, int blocks_per_tile,
                            const int* __restrict__ dyn) {
-  group_walk<T, POLICY, true, false, BIG>(stream, vals, chunk_meta, Bp, Cv, P, nchunks, k, col_tile, ldb, stream_nt, blocks_per_tile, dyn);
+  group_walk<POLICY, true, false, BIG>(stream, vals, chunk_meta, Bp, Cv, P, nchunks, T, k, col_tile, ldb, stream_nt, blocks_per_tile, dyn);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -264,12 +265,11 @@ __device__ __forceinline__ int row_ror8_bcast(int v, int vrot, bool upper) {   /
   return upper ? hi : lo;
 }
 
-template <int T, bool RING, bool VALS, bool BIG>
+template <bool RING, bool VALS, bool BIG>
 __device__ __forceinline__ void
 group8_walk(const unsigned short* __restrict__ stream, const float* __restrict__ vals, const int2* __restrict__ chunk_meta,
             const float* __restrict__ Bp, float* __restrict__ Cv, float* __restrict__ P,
-            int nchunks, int k, int ldb, int stream_nt, const int* __restrict__ dyn) {
-  static_assert(T % 64 == 0, "a chunk is whole runs of 64 entries");
+            int nchunks, int T, int k, int ldb, int stream_nt, const int* __restrict__ dyn) {
   if (dyn) { if (dyn[0] == 0) return; nchunks = dyn[1]; }      // (as group_walk)
   const int lane = threadIdx.x & 63;
   const int wib  = threadIdx.x >> 6;
@@ -441,21 +441,21 @@ group8_walk(const unsigned short* __restrict__ stream, const float* __restrict__
   }
 }
 
-template <int T, bool RING, bool BIG>
+template <bool RING, bool BIG>
 __global__ void __launch_bounds__(256)
 spmm_group8_kernel(const unsigned short* __restrict__ stream, const int2* __restrict__ chunk_meta,
                    const float* __restrict__ Bp, float* __restrict__ Cv, float* __restrict__ P,
-                   int nchunks, int k, int ldb, int stream_nt, const int* __restrict__ dyn) {
-  group8_walk<T, RING, false, BIG>(stream, nullptr, chunk_meta, Bp, Cv, P, nchunks, k, ldb, stream_nt, dyn);
+                   int nchunks, int T, int k, int ldb, int stream_nt, const int* __restrict__ dyn) {
+  group8_walk<RING, false, BIG>(stream, nullptr, chunk_meta, Bp, Cv, P, nchunks, T, k, ldb, stream_nt, dyn);
 }
 
 // ... and with the values beside the stream (matrices whose values do not factor); no ring: 138 VGPRs without
-template <int T, bool BIG>
+template <bool BIG>
 __global__ void __launch_bounds__(256)
 spmm_group8_weighted_kernel(const unsigned short* __restrict__ stream, const float* __restrict__ vals,
                             const int2* __restrict__ chunk_meta, const float* __restrict__ Bp, float* __restrict__ Cv,
-                            float* __restrict__ P, int nchunks, int k, int ldb, int stream_nt, const int* __restrict__ dyn) {
-  group8_walk<T, false, true, BIG>(stream, vals, chunk_meta, Bp, Cv, P, nchunks, k, ldb, stream_nt, dyn);
+                            float* __restrict__ P, int nchunks, int T, int k, int ldb, int stream_nt, const int* __restrict__ dyn) {
+  group8_walk<false, true, BIG>(stream, vals, chunk_meta, Bp, Cv, P, nchunks, T, k, ldb, stream_nt, dyn);
 }
 
 // 32-bit byte offsets (entry + slice base) * row_bytes reach every row of the sliced copy?  (__umul24: both factors
@@ -482,19 +482,19 @@ bool spmm_group8_applies(const GroupArgs& a) {
 
 namespace {
 
-template <int T, bool BIG>
+template <bool BIG>
 hipError_t launch_group8_t(const GroupArgs& a, int ldb, hipStream_t s) {
   const int per_xcd = a.nchunks / 8;
   const int stream_nt8 = (size_t)a.nchunks * (size_t)a.T * (a.vals ? 6u : 2u) > ((size_t)64 << 20) ? 1 : 0;
   const int nb8 = 8 * ((per_xcd + 31) / 32);
   const int2* meta = reinterpret_cast<const int2*>(a.chunk_meta);
-  if (a.vals)      spmm_group8_weighted_kernel<T, BIG><<<dim3(nb8), dim3(256), 0, s>>>(a.stream, a.vals, meta, a.Bp, a.Cv, a.P, a.nchunks, a.k, ldb, stream_nt8, a.dyn);
-  else if (a.ring) spmm_group8_kernel<T, true, BIG><<<dim3(nb8), dim3(256), 0, s>>>(a.stream, meta, a.Bp, a.Cv, a.P, a.nchunks, a.k, ldb, stream_nt8, a.dyn);
-  else             spmm_group8_kernel<T, false, BIG><<<dim3(nb8), dim3(256), 0, s>>>(a.stream, meta, a.Bp, a.Cv, a.P, a.nchunks, a.k, ldb, stream_nt8, a.dyn);
+  if (a.vals)      spmm_group8_weighted_kernel<BIG><<<dim3(nb8), dim3(256), 0, s>>>(a.stream, a.vals, meta, a.Bp, a.Cv, a.P, a.nchunks, a.T, a.k, ldb, stream_nt8, a.dyn);
+  else if (a.ring) spmm_group8_kernel<true, BIG><<<dim3(nb8), dim3(256), 0, s>>>(a.stream, meta, a.Bp, a.Cv, a.P, a.nchunks, a.T, a.k, ldb, stream_nt8, a.dyn);
+  else             spmm_group8_kernel<false, BIG><<<dim3(nb8), dim3(256), 0, s>>>(a.stream, meta, a.Bp, a.Cv, a.P, a.nchunks, a.T, a.k, ldb, stream_nt8, a.dyn);
   return hipGetLastError();
 }
 
-template <int T, int POLICY, bool BIG>
+template <int POLICY, bool BIG>
 hipError_t launch_group_tp(const GroupArgs& a, int ldb, hipStream_t s) {
   const int per_xcd = a.nchunks / 8;
   int nblocks = 8 * ((per_xcd + 15) / 16);
@@ -509,40 +509,29 @@ hipError_t launch_group_tp(const GroupArgs& a, int ldb, hipStream_t s) {
   const int2* meta = reinterpret_cast<const int2*>(a.chunk_meta);
   for (int t = 0; t < tiles; t += tiles_per_launch) {
     if (a.vals)
-      spmm_group_weighted_kernel<T, POLICY, BIG><<<dim3(nblocks), dim3(256), 0, s>>>(a.stream, a.vals, meta, a.Bp, a.Cv, a.P, a.nchunks, a.k, t, ldb, stream_nt, blocks_per_tile, a.dyn);
+      spmm_group_weighted_kernel<POLICY, BIG><<<dim3(nblocks), dim3(256), 0, s>>>(a.stream, a.vals, meta, a.Bp, a.Cv, a.P, a.nchunks, a.T, a.k, t, ldb, stream_nt, blocks_per_tile, a.dyn);
     else if (a.ring)
-      spmm_group_ring_kernel<T, POLICY, BIG><<<dim3(nblocks), dim3(256), 0, s>>>(a.stream, meta, a.Bp, a.Cv, a.P, a.nchunks, a.k, t, ldb, stream_nt, blocks_per_tile, a.dyn);
+      spmm_group_ring_kernel<POLICY, BIG><<<dim3(nblocks), dim3(256), 0, s>>>(a.stream, meta, a.Bp, a.Cv, a.P, a.nchunks, a.T, a.k, t, ldb, stream_nt, blocks_per_tile, a.dyn);
     else
-      spmm_group_kernel<T, POLICY, BIG><<<dim3(nblocks), dim3(256), 0, s>>>(a.stream, meta, a.Bp, a.Cv, a.P, a.nchunks, a.k, t, ldb, stream_nt, blocks_per_tile, a.dyn);
+      spmm_group_kernel<POLICY, BIG><<<dim3(nblocks), dim3(256), 0, s>>>(a.stream, meta, a.Bp, a.Cv, a.P, a.nchunks, a.T, a.k, t, ldb, stream_nt, blocks_per_tile, a.dyn);
   }
   return hipGetLastError();
-}
-
-template <int T>
-hipError_t launch_group_t(const GroupArgs& a, int ldb, bool big, hipStream_t s) {
-  if (spmm_group8_applies(a)) return big ? launch_group8_t<T, true>(a, ldb, s) : launch_group8_t<T, false>(a, ldb, s);
-  if (big) return launch_group_tp<T, 2, true>(a, ldb, s);            // (the store policy is a tuning knob: BIG keeps the default)
-  if (a.store_policy == 1) return launch_group_tp<T, 1, false>(a, ldb, s);
-  if (a.store_policy == 2) return launch_group_tp<T, 2, false>(a, ldb, s);
-  return launch_group_tp<T, 0, false>(a, ldb, s);
 }
 
 }  // namespace
 
 hipError_t launch_spmm_group(const GroupArgs& a, hipStream_t s) {
   if (a.nchunks <= 0 || a.k <= 0) return hipSuccess;
-  if (a.nchunks % 32 != 0 || a.k % 4 != 0) return hipErrorInvalidValue;
+  if (a.nchunks % 32 != 0 || a.k % 4 != 0 || a.T < 64 || a.T % 64 != 0) return hipErrorInvalidValue;
   const int ldb = a.ldb > 0 ? a.ldb : a.k;
   if (a.table_rows <= 0) return hipErrorInvalidValue;                 // (the addressing mode depends on it)
   const bool big = spmm_group_needs_big(a.table_rows, ldb);
   if (big && ldb * 4 >= (1 << 17)) return hipErrorInvalidValue;
-  switch (a.T) {
-    case 256:  return launch_group_t<256>(a, ldb, big, s);
-    case 512:  return launch_group_t<512>(a, ldb, big, s);
-    case 1024: return launch_group_t<1024>(a, ldb, big, s);
-    case 2048: return launch_group_t<2048>(a, ldb, big, s);
-    default: return hipErrorInvalidValue;
-  }
+  if (spmm_group8_applies(a)) return big ? launch_group8_t<true>(a, ldb, s) : launch_group8_t<false>(a, ldb, s);
+  if (big) return launch_group_tp<2, true>(a, ldb, s);               // (the store policy is a tuning knob: BIG keeps the default)
+  if (a.store_policy == 1) return launch_group_tp<1, false>(a, ldb, s);
+  if (a.store_policy == 2) return launch_group_tp<2, false>(a, ldb, s);
+  return launch_group_tp<0, false>(a, ldb, s);
 }
 
 }  // namespace gcn

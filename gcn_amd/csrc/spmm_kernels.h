@@ -136,6 +136,11 @@ hipError_t device_csr_apply_rank(const int* rowptr, const int* col, const float*
                                  int nnz, int* out_rowptr, int* out_col, float* out_val, int* vomp_out,
                                  int* bad_rank_host, hipStream_t st);
 
+// rabbit_device.hip — Rabbit ordering by parallel incremental aggregation (Arai et al., IPDPS 2016; renumber.cu:328-330);
+// rowptr/col: SYMMETRIC pattern (self-loops ignored); stats_host[4] = {communities, passes, retried, left top-level}
+hipError_t device_order_rabbit(const int* rowptr, const int* col, int n, int nnz, int* rank_out_dev, int* community_out_dev,
+                               long long* stats_host, hipStream_t st);
+
 // slicing.hip
 // 16-bit column stream of a sliced CSR (S <= 8, slice width <= 65 535): every slice padded to a multiple of T
 // with 0xFFFF markers; vrowptr16 [S*m+1] (the last row of a slice owns its markers), col16 [*nnz16_host],

@@ -133,7 +133,11 @@ class GCN(nn.Module):
         self.output = None
         self.adj = self.features = self.labels = self.vo_mp = None
         self.tuning = None                    # {slices: ms} measured by prepare() on a renumbered graph
-        self.dropout_seed, self._dropout_calls = 0x5EED, 0
+        # fused-epilogue dropout: Philox keyed on (seed, offset).  The seed is drawn from torch's default generator at
+        # the first training forward (so torch.manual_seed governs it like F.dropout's masks, two models or two
+        # restarts differ unless seeded alike), the offset counts forward passes; both are part of state_dict-less
+        # extra state (get_extra_state) so a checkpoint resumes the same mask sequence
+        self.dropout_seed, self._dropout_calls = None, 0
         self.dur_fwd = timers.Timer()
 
     def reset_timing(self):
@@ -145,6 +149,8 @@ class GCN(nn.Module):
         with self.dur_fwd:
             if self.fuse_epilogue and self.training and self.dropout > 0:
                 # bias + ReLU + dropout mask in the SpMM epilogue; a fresh Philox offset per forward pass
+                if self.dropout_seed is None:
+                    self.dropout_seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
                 self._dropout_calls += 1
                 x = self.gc1(x, adj, relu=self.with_relu, fuse_epilogue=True,
                              dropout=(float(self.dropout), self.dropout_seed, self._dropout_calls))
@@ -153,6 +159,12 @@ class GCN(nn.Module):
                 x = F.dropout(x, self.dropout, training=self.training)
             x = self.gc2(x, adj)
             return F.log_softmax(x, dim=1)
+
+    def get_extra_state(self):
+        return {"dropout_seed": self.dropout_seed, "dropout_calls": self._dropout_calls}
+
+    def set_extra_state(self, state):
+        self.dropout_seed, self._dropout_calls = state.get("dropout_seed"), int(state.get("dropout_calls", 0))
 
     def initialize(self):
         self.gc1.reset_parameters()

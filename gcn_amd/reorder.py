@@ -159,6 +159,67 @@ def apply_rank_device(rowptr, col, vals, rank):
     return o_rp, o_ci, o_va, vomp
 
 
+def order_rabbit(rowptr, col, return_communities=False):
+    """The serial Rabbit of the reference (renumber.cu:319-520) without the CSR rewrite: rank[old]=new (int64; the
+    inverse of the vomp the `rabbit` symbol returns) and, on request, the top-level vertex of every vertex."""
+    rowptr, col, n, nnz = _csr(rowptr, col)
+    vomp = np.empty(n, dtype=np.int32)
+    comm = np.empty(n, dtype=np.int32) if return_communities else None
+    _lib.check(_lib.load().gcn_order_rabbit(_p(rowptr), _p(col), n, nnz, _p(vomp), _p(comm) if comm is not None else None),
+               "gcn_order_rabbit")
+    rank = np.empty(n, dtype=np.int64)
+    rank[vomp] = np.arange(n)
+    return (rank, comm) if return_communities else rank
+
+
+def order_rabbit_device(rowptr, col, return_communities=False, return_stats=False):
+    """Rabbit on the GPU — parallel incremental aggregation (Arai et al. 2016, the algorithm renumber.cu:328-330 names;
+    csrc/rabbit_device.hip).  CUDA int32 CSR of a SYMMETRIC pattern in, int64 rank[old]=new on the same device out.
+    Not the serial code's integers (use `rabbit` / `order_rabbit` for those) and not bit-reproducible between runs;
+    its communities reach the serial version's modularity to a few percent.
+    → rank [, communities (top-level vertex per vertex)] [, dict(communities, passes, retried, left_top_level)]"""
+    import torch
+    if not rowptr.is_cuda:
+        raise _lib.GcnAmdError("order_rabbit_device needs CUDA/HIP tensors (the host version is order_rabbit)")
+    n = rowptr.numel() - 1
+    rp, ci = rowptr.to(torch.int32).contiguous(), col.to(torch.int32).contiguous()
+    rank = torch.empty(n, dtype=torch.int32, device=rowptr.device)
+    comm = torch.empty(n, dtype=torch.int32, device=rowptr.device) if return_communities else None
+    stats = (ctypes.c_int64 * 4)()
+    with torch.cuda.device(rowptr.device):
+        _lib.check(_lib.load().gcn_order_rabbit_device(
+            ctypes.c_void_p(rp.data_ptr()), ctypes.c_void_p(ci.data_ptr()), n, int(ci.numel()),
+            ctypes.c_void_p(rank.data_ptr()), ctypes.c_void_p(comm.data_ptr()) if comm is not None else None,
+            ctypes.cast(stats, ctypes.c_void_p), ctypes.c_void_p(torch.cuda.current_stream(rowptr.device).cuda_stream)),
+            "gcn_order_rabbit_device")
+    out = [rank.to(torch.int64)]
+    if return_communities:
+        out.append(comm.to(torch.int64))
+    if return_stats:
+        out.append(dict(communities=int(stats[0]), passes=int(stats[1]), retried=int(stats[2]), left_top_level=int(stats[3])))
+    return out[0] if len(out) == 1 else tuple(out)
+
+
+def modularity(rowptr, col, communities):
+    """Newman modularity Q of a partition of an undirected graph given as a symmetric CSR pattern (self-loops ignored,
+    unit weights — what Rabbit maximises, renumber.cu:454-470): Σ_c [ in_c / 2m − (deg_c / 2m)² ] with in_c the stored
+    entries inside community c and deg_c the sum of its vertices' degrees.  torch tensors on any device → float"""
+    import torch
+    n = rowptr.numel() - 1
+    rows = torch.repeat_interleave(torch.arange(n, device=col.device), (rowptr[1:] - rowptr[:-1]).long())
+    cols = col.long()
+    keep = rows != cols
+    rows, cols = rows[keep], cols[keep]
+    c = communities.to(device=col.device, dtype=torch.int64)
+    two_m = float(rows.numel())
+    if two_m == 0:
+        return 0.0
+    cr = c[rows]
+    inside = torch.bincount(cr[cr == c[cols]], minlength=n).double()
+    deg = torch.bincount(cr, minlength=n).double()
+    return float((inside / two_m - (deg / two_m) ** 2).sum())
+
+
 def order_communities_device(rowptr, col, max_rounds=24, min_merge_frac=0.002, return_levels=False):
     """A GPU community ordering in the spirit of Rabbit (incremental modularity aggregation,
     renumber.cu:319-522 / Arai et al. 2016) — SURVEY §8f.4's "parallel Rabbit", opt-in: it is NOT the

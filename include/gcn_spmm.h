@@ -245,6 +245,11 @@ int gcn_order_rcm(const int32_t* rowptr, const int32_t* col, int32_t n, int32_t 
                   int32_t directed, int64_t* rank_out);
 int gcn_order_gorder(const int32_t* rowptr, const int32_t* col, int32_t n, int32_t nnz,
                      int32_t window, int64_t* rank_out);
+/* rabbit (renumber.cu:319-520: serial modularity merging, rounds in degree order) WITHOUT the CSR rewrite the
+ * drop-in symbol does: vomp_out[new] = old (bit-exact with the reference) and, optionally, the surviving top-level
+ * vertex every vertex ended under (community_out; what the parallel version's quality is measured against). */
+int gcn_order_rabbit(const int32_t* rowptr, const int32_t* col, int32_t n, int32_t nnz, int32_t* vomp_out,
+                     int32_t* community_out);
 /* CSR rewrite under a rank: rows/cols relabelled, each row's columns sorted
  * ascending with values carried along (renumber.cu:190-217); vomp_out[new]=old. */
 int gcn_csr_apply_rank(int32_t* rowptr, int32_t* col, float* vals, int32_t n, int32_t nnz,
@@ -269,6 +274,17 @@ int gcn_order_rcm_device(const int32_t* rowptr_dev, const int32_t* col_dev, int3
 int gcn_csr_apply_rank_device(const int32_t* rowptr_dev, const int32_t* col_dev, const float* val_dev,
                               const int32_t* rank_dev, int32_t n, int32_t nnz, int32_t* out_rowptr_dev,
                               int32_t* out_col_dev, float* out_val_dev, int32_t* vomp_out_dev, void* stream);
+/* Rabbit ON THE DEVICE: the parallel algorithm the reference's serial code cites as "Rabbit properly" (renumber.cu:
+ * 328-330: Arai et al., IPDPS 2016) — every vertex once, in ascending degree order, one wave per vertex; lazy
+ * aggregation of the merged vertices' (community, weight) lists; the merge itself is one compare-and-swap on the
+ * target's {lock, degree, child} word (csrc/rabbit_device.hip).  NOT the serial code's integers (gcn_order_rabbit /
+ * the `rabbit` symbol give those) and not bit-reproducible from run to run (which merges race differs): what is
+ * guaranteed is a permutation whose communities reach the serial version's modularity to a few percent (tests).
+ * Input: a SYMMETRIC pattern (A = Aᵀ; self-loops ignored; values play no part, as in the reference).
+ * rank_out_dev[old] = new; community_out_dev (may be NULL): top-level vertex of every vertex; stats_host (may be NULL):
+ * {communities, passes, vertices retried, vertices left top-level for lack of table or pool room}. */
+int gcn_order_rabbit_device(const int32_t* rowptr_dev, const int32_t* col_dev, int32_t n, int32_t nnz,
+                            int32_t* rank_out_dev, int32_t* community_out_dev, int64_t* stats_host, void* stream);
 
 /* ------------------------------------------------------------------------- */
 /* (2) DROP-IN symbols — identical names and argument lists to the reference.  */

@@ -187,6 +187,19 @@ def test_training_with_the_fully_fused_epilogue():
     model = gcn_amd.GCN(f, 16, c, dataset="synthetic", device="cuda:0", order=None, dropout=0.5, fuse_epilogue=True).to("cuda:0")
     losses = model.fit(X, A, labels, idx_train, train_iters=60)
     assert losses[-1] < 0.6 * losses[0] and model._dropout_calls == 60
+    # the mask sequence follows torch's generator: same manual_seed -> same seed, another -> another;
+    # and it travels with the state dict
+    seed1 = model.dropout_seed
+    assert seed1 is not None and model.state_dict()["_extra_state"] == {"dropout_seed": seed1, "dropout_calls": 60}
+    seeds = []
+    for ms in (15, 15, 16):
+        torch.manual_seed(ms)
+        m2 = gcn_amd.GCN(f, 16, c, dataset="synthetic", device="cuda:0", order=None, dropout=0.5, fuse_epilogue=True).to("cuda:0")
+        m2.fit(X, A, labels, idx_train, train_iters=1)
+        seeds.append(m2.dropout_seed)
+    assert seeds[0] == seeds[1] == seed1 and seeds[2] != seeds[0]
+    m2.load_state_dict(model.state_dict())
+    assert m2.dropout_seed == seed1 and m2._dropout_calls == 60
     idx_test = np.setdiff1d(np.arange(n), idx_train)[:1000]
     assert float(model.test(idx_test, labels)) > 0.6
 

@@ -177,3 +177,35 @@ def test_gpu_style_community_ordering_is_a_permutation_that_groups_planted_commu
     # degenerate inputs
     e = torch.zeros(5, dtype=torch.int32)
     assert reorder.order_communities_device(torch.zeros(5, dtype=torch.int32), e[:0]).tolist() == [0, 1, 2, 3]
+
+
+@pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p)[8:-4] for p in CASES])
+def test_order_rabbit_without_the_rewrite_gives_the_reference_vomp_and_its_communities(path):
+    """gcn_order_rabbit: the serial Rabbit as a rank (no CSR rewrite) — the inverse of the vomp recorded from the
+    reference's compiled code — plus the top-level vertex of every vertex: communities are contiguous in the new
+    order, their top-level vertex is a member, and the modularity helper agrees with a dense evaluation"""
+    import torch
+    g = np.load(path)
+    rp, ci = g["rowptr"], g["col"]
+    n = len(rp) - 1
+    rank, comm = reorder.order_rabbit(rp, ci, return_communities=True)
+    assert np.array_equal(rank[g["rabbit_vomp"]], np.arange(n))              # bit-exact with the reference's order
+    assert np.array_equal(reorder.order_rabbit(rp, ci), rank)
+    in_new_order = comm[g["rabbit_vomp"]]
+    changes = int((np.diff(in_new_order) != 0).sum())
+    assert changes == len(np.unique(comm)) - 1                               # every community one contiguous run
+    assert np.array_equal(comm[np.unique(comm)], np.unique(comm))            # a top-level vertex belongs to itself
+    # modularity against a dense evaluation on the symmetrised, loop-free pattern
+    A = sp.csr_matrix((np.ones(len(ci)), ci, rp), shape=(n, n)); A = ((A + A.T) > 0).astype(np.float64).tolil()
+    A.setdiag(0); A = A.tocsr()
+    two_m = A.sum()
+    if two_m > 0:
+        deg = np.asarray(A.sum(1)).ravel()
+        q = 0.0
+        for c in np.unique(comm):
+            mem = np.flatnonzero(comm == c)
+            q += A[mem][:, mem].sum() / two_m - (deg[mem].sum() / two_m) ** 2
+        As = A.tocsr(); As.sort_indices()
+        got = reorder.modularity(torch.from_numpy(As.indptr.astype(np.int32)), torch.from_numpy(As.indices.astype(np.int32)),
+                                 torch.from_numpy(comm))
+        assert abs(got - q) <= 1e-9
