@@ -128,7 +128,7 @@ class GCN(nn.Module):
         self.dropout, self.lr = dropout, lr
         self.weight_decay = weight_decay if with_relu else 0
         self.with_relu, self.with_bias = with_relu, with_bias
-        self.order = order                    # None | "dfs" | "gorder" | "rabbit" (gcn6.py:27-30: RBT default) | "rcm" | "deg" (GPU)
+        self.order = order                    # None | "dfs" | "gorder" | "rabbit" (gcn6.py:27-30: RBT default) | "rcm" | "deg" | "rabbit_device" (GPU)
         self.fuse_epilogue = fuse_epilogue
         self.output = None
         self.adj = self.features = self.labels = self.vo_mp = None
@@ -179,12 +179,13 @@ class GCN(nn.Module):
         adj_norm = preprocess.normalize_adj_tensor(adj) if normalize else preprocess.sparse_mx_to_torch_sparse_tensor(adj)
         rp, ci, va, vo_mp = preprocess.to_csr_int32(adj_norm)
         dev = torch.device(self.device)
-        if self.order in ("rcm", "deg", "communities"):                          # step 1 on the GPU
+        if self.order in ("rcm", "deg", "communities", "rabbit_device"):          # step 1 on the GPU
             # the reference library's internal orderings (order_rcm.cu, order_deg.cu), computed by the
             # device kernels — same integers as the host code, ~100x faster (reorder_device.hip)
             rp, ci, va = rp.to(dev), ci.to(dev), va.to(dev)
             rank = (reorder.order_rcm_device(rp, ci) if self.order == "rcm"
                     else reorder.order_communities_device(rp, ci) if self.order == "communities"
+                    else reorder.order_rabbit_device(rp, ci) if self.order == "rabbit_device"    # parallel Rabbit (Arai'16)
                     else reorder.order_deg_device(rp, ci, "total", True))
             rp, ci, va, vo_mp = reorder.apply_rank_device(rp, ci, va, rank)
         else:

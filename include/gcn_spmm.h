@@ -290,6 +290,10 @@ int gcn_order_rabbit_device(const int32_t* rowptr_dev, const int32_t* col_dev, i
 /* (2) DROP-IN symbols — identical names and argument lists to the reference.  */
 /* ------------------------------------------------------------------------- */
 
+/* Error convention of every drop-in symbol: the reference's (void, print — cuspmm.cu:3-21).  On malformed input,
+ * foreign buffers or a HIP failure ONE line goes to stderr ("libgcnspmm: <symbol>: ...") and the call RETURNS with
+ * the caller's outputs untouched; nothing aborts the host process. */
+
 /* renumber.so — renumber.cu:23 (dfs), :157 (gorder), :233 (perm_apply), :319 (rabbit).
  * All pointers HOST, CSR rewritten in place, vomp[new] = old. */
 void dfs(int* rowPtr, int* col, float* vals, int* vomp, int m, int n, int nnz);
@@ -301,15 +305,20 @@ void rabbit(int* rowPtr, int* col, float* vals, int* vomp, int m, int n, int nnz
  * (not the reference's defective tile-seg arrays, SURVEY defects D1-D3) into the
  * caller's buffers; capacities honoured: seg_rowPtr nnz ints, segNzCV 2*nnz
  * floats, segVoMap nnz ints, grouped_tailSeg/next_seg 256 ints (gcn6.py:334-339).
- * Encoding documented in INTEGRATION.md. */
+ * n_segs[0] = nnz / 9, or one less so that its lowest bit tells flexspmm whether the values are u[r]*u[c] (n_segs is the
+ * only scalar gcn6 carries from csr2tile to flexspmm, gcn6.py:353-366); needs nnz >= m + 19, else nothing is packed
+ * and n_segs[0] = 0.  Encoding documented in INTEGRATION.md. */
 void csr2tile(int* rowPtr, int* colIdx, float* vals, int m, int n, int nnz,
               int* vo_mp, int* segVoMap, int* seg_rowPtr, float* segNzCV,
               int* grouped_tailSeg, int* next_seg, int tm, int* n_segs);
 
 /* flexspmm.so — flexspmm.cu:499-502.  All pointers DEVICE.  Consumes the arrays
  * written by this library's csr2tile (plain CSR, or — square graphs that qualify for XCD-aware slicing — the group
- * kernels' stream format).  Legacy default stream; in the group format one 64-byte header is
- * copied back synchronously per call, and buffers without it are refused (message + abort). */
+ * kernels' stream format).  Like the reference's (flexspmm.cu:497-540) the call only ENQUEUES
+ * kernels on the legacy default stream (flexspmm.cu:512): in the group format the chunk and cut-row counts are read
+ * from the packed header ON THE DEVICE by a one-thread guard kernel (grids sized from upper bounds) — no layer drains
+ * the stream.  Only the first call on a given set of buffers reads the 64-byte header once, to report buffers this
+ * library did not pack (message, return, C as handed over); a header that disappears later is caught by the guard. */
 void flexspmm(int* seg_rowPtr, float* segNzCV, int* segVoMap,
               int* grouped_tailSeg, int* next_seg,
               int m, int n, int k, int n_segs, float* B, float* C);

@@ -29,7 +29,7 @@ def _load_weights(model, g):
         model.gc2.weight.copy_(torch.from_numpy(g["w2"])); model.gc2.bias.copy_(torch.from_numpy(g["b2"]))
 
 
-@pytest.mark.parametrize("order", [None, "dfs", "gorder", "rabbit", "rcm", "deg", "communities"])
+@pytest.mark.parametrize("order", [None, "dfs", "gorder", "rabbit", "rcm", "deg", "communities", "rabbit_device"])
 @pytest.mark.parametrize("fused", [False, True])
 def test_forward_matches_the_python_reference_output(order, fused):
     """gcn1's recorded log-softmax output (both layers A(XW), dataset 'pubmed' selects that order,
