@@ -30,6 +30,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <time.h>
 #include <vector>
 #include "spmm_kernels.h"
 
@@ -68,9 +69,13 @@ struct RabbitArgs {
   unsigned* retry; unsigned* nretry;                             // ... and the next pass's
   unsigned* bkey; unsigned* bval; unsigned* btouch;              // per wave: kBigCap slots + the list of slots in use
   unsigned* skipped;                                             // vertices whose lists did not fit (left top-level)
+  unsigned* beat;                                                // GCN_AMD_RABBIT_BEAT=1: per wave {vertex, stage, x} watched from the host; null: off
   unsigned* dbg;                                                 // [4] guard trips: pointer chains, child chains, full table (all 0 in a sound run)
   double two_m_inv;
 };
+
+#define GCN_BEAT(a_, lane_, stage_, x_) do { if ((a_).beat && (lane_) == 0) { st_u32((a_).beat + 4 * blockIdx.x + 1, (stage_)); \
+  st_u32((a_).beat + 4 * blockIdx.x + 2, (unsigned)(x_)); } } while (0)
 
 // current community of x: follow the merge pointers (they only ever move up, so a stale value still names an ancestor)
 __device__ __forceinline__ unsigned find_root(unsigned* dest, unsigned x, unsigned* dbg) {
@@ -78,7 +83,7 @@ __device__ __forceinline__ unsigned find_root(unsigned* dest, unsigned x, unsign
   if (p == x) return x;
   const unsigned x0 = x;
   int guard = 1 << 16;                                // (chains are short; a bound so that no wave can ever spin for good)
-  do { x = p; p = ld_u32(dest + x); } while (p != x && --guard > 0);
+  do { x = p; p = ld_u32(dest + x); } while (p != x && --guard > 0);   // (every value ever stored in dest is a vertex id)
   if (guard <= 0) atomicAdd(dbg + 0, 1u);
   st_u32(dest + x0, x);                               // one-step shortcut (benign race: any ancestor is a valid value)
   return x;
@@ -124,10 +129,14 @@ __device__ __noinline__ void rabbit_vertex(const RabbitArgs& a, Table<LDS> t, un
   // starts from the list it aggregated then — every list is folded once — plus the children merged since.
   const unsigned own_len = a.agg_len[u];
   const unsigned covered = own_len ? a.agg_child[u] : kNone;
+  const unsigned nverts = (unsigned)a.n;
   if (own_len) {
-    const unsigned long long* lst = a.pool + a.agg_ptr[u];
-    for (unsigned i = lane; i < own_len; i += 64) {
+    const unsigned long long op = a.agg_ptr[u];
+    const unsigned long long* lst = a.pool + op;
+    const unsigned len = op + own_len <= a.pool_cap ? own_len : 0u;
+    for (unsigned i = lane; i < len; i += 64) {
       const unsigned long long kw = lst[i];             // (written by this vertex's own earlier step: a kernel boundary ago)
+      if ((unsigned)(kw >> 32) >= nverts) { atomicAdd(a.dbg + 3, 1u); continue; }   // (never, in a sound run: an index is checked before it is followed)
       const unsigned r = find_root(a.dest, (unsigned)(kw >> 32), a.dbg);
       if (r != u) t.add(r, (unsigned)kw);
     }
@@ -140,15 +149,22 @@ __device__ __noinline__ void rabbit_vertex(const RabbitArgs& a, Table<LDS> t, un
       if (r != u) t.add(r, 1u);
     }
   }
+  int walked = 0;
   for (unsigned c = child; c != kNone && c != covered; c = ld_u32(a.sibling + c)) {
-    const unsigned long long* lst = a.pool + ld_u64(a.agg_ptr + c);
-    const unsigned len = ld_u32(a.agg_len + c);
+    if (c >= nverts || ++walked > a.n) { if (lane == 0) atomicAdd(a.dbg + 1, 1u); break; }
+    const unsigned long long cp = ld_u64(a.agg_ptr + c);
+    const unsigned clen = ld_u32(a.agg_len + c);
+    const unsigned long long* lst = a.pool + cp;
+    const unsigned len = cp + clen <= a.pool_cap ? clen : 0u;
+    if (len != clen && lane == 0) atomicAdd(a.dbg + 3, 1u);
     for (unsigned i = lane; i < len; i += 64) {
       const unsigned long long kw = ld_u64(lst + i);
+      if ((unsigned)(kw >> 32) >= nverts) { atomicAdd(a.dbg + 3, 1u); continue; }
       const unsigned r = find_root(a.dest, (unsigned)(kw >> 32), a.dbg);
       if (r != u) t.add(r, (unsigned)kw);
     }
   }
+  GCN_BEAT(a, lane, 4, 0);
   __syncthreads();
   // 4. walk the entries: best gain, number of entries.  (LDS: the whole table; memory: the slots on the touch list)
   const unsigned nslots = LDS ? (unsigned)kLdsCap : *ntouch_lds;
@@ -160,6 +176,7 @@ __device__ __noinline__ void rabbit_vertex(const RabbitArgs& a, Table<LDS> t, un
     const unsigned k = t.peek(i);
     if (k == kNone) continue;
     ++mine;
+    if (k >= (unsigned)a.n) continue;
     const double dq = (double)t.weight(i) - (double)atom_deg(ld_u64(a.atom + k)) * du_2m;
     if (dq > best || (dq == best && dq > 0.0 && k < bestv)) { best = dq; bestv = k; }
   }
@@ -168,6 +185,7 @@ __device__ __noinline__ void rabbit_vertex(const RabbitArgs& a, Table<LDS> t, un
     const unsigned ov = __shfl_xor(bestv, off);
     if (ob > best || (ob == best && ob > 0.0 && ov < bestv)) { best = ob; bestv = ov; }
   }
+  GCN_BEAT(a, lane, 5, bestv);
   // 5. the entries leave the table (into the pool when u is going to be merged); the table is empty again
   unsigned incl = mine;                               // inclusive prefix of the lanes' counts
   for (int off = 1; off < 64; off <<= 1) {
@@ -175,7 +193,7 @@ __device__ __noinline__ void rabbit_vertex(const RabbitArgs& a, Table<LDS> t, un
     if (lane >= off) incl += tt;
   }
   const unsigned cnt = __shfl(incl, 63);
-  const bool merging = bestv != kNone && best > 0.0;
+  const bool merging = bestv < (unsigned)a.n && best > 0.0;
   unsigned long long base = 0;
   bool stored = false;
   if (merging) {
@@ -194,6 +212,7 @@ __device__ __noinline__ void rabbit_vertex(const RabbitArgs& a, Table<LDS> t, un
     t.clear(i);
   }
   __syncthreads();
+  GCN_BEAT(a, lane, 6, cnt);
   if (lane == 0) {
     *ntouch_lds = 0;
     bool done = false;
@@ -241,11 +260,21 @@ rabbit_pass_kernel(RabbitArgs a) {
     idx = (unsigned)__builtin_amdgcn_readfirstlane((int)idx);
     if (idx >= a.count) break;
     const unsigned u = a.list[idx];
+    if (a.beat && lane == 0) st_u32(a.beat + 4 * blockIdx.x, u);
+    GCN_BEAT(a, lane, 1, idx);
     // 1. lock u: nobody merges into it from here on; its degree and child list are final for this step
     unsigned long long au = 0;
     if (lane == 0) au = atomicOr(&a.atom[u], kLock);
     au = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(au >> 32)) << 32) |
          (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)au);
+    // ACQUIRE at device scope: everything the vertices merged into u published before their compare-and-swap (their
+    // sibling links, list pointers and lengths, the lists themselves — released by the fence in front of that CAS) must be
+    // read from memory, not from a copy this XCD's L2 happens to hold from before: the 8 L2s are not coherent with each
+    // other, and a relaxed load may hit such a line.  (Found the hard way: a stale list pointer or list entry is an
+    // arbitrary integer, and following it faults.)
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    if (au & kLock) continue;       // (already locked: merged away, or in another wave's hands — never the case for a vertex
+                                    //  handed out once; cheap insurance, and the lock is not ours to release)
     const unsigned du = atom_deg(au);
     // 2. how long are the lists to aggregate?  (own row + the lists of the vertices merged into u so far)
     const unsigned own_len = a.agg_len[u];
@@ -253,9 +282,11 @@ rabbit_pass_kernel(RabbitArgs a) {
     unsigned long long total = own_len ? (unsigned long long)own_len : (unsigned long long)(a.rowptr[u + 1] - a.rowptr[u]);
     int chain = 0;
     for (unsigned c = atom_child(au); c != kNone && c != covered; c = ld_u32(a.sibling + c)) {
+      if (c >= (unsigned)a.n) { if (lane == 0) atomicAdd(a.dbg + 1, 1u); total = ~0ull >> 1; break; }
       total += ld_u32(a.agg_len + c);
       if (++chain > a.n) { if (lane == 0) atomicAdd(a.dbg + 1, 1u); total = ~0ull >> 1; break; }   // (a child list longer than n: broken)
     }
+    GCN_BEAT(a, lane, 2, total);
     if (du == 0 || total > (unsigned long long)kBigCap / 2) {
       // isolated, or too long even for the table in memory (hubs of hubs): stays top-level
       if (lane == 0) {
@@ -270,13 +301,16 @@ rabbit_pass_kernel(RabbitArgs a) {
                      a.btouch + (size_t)wave * (kBigCap / 2), &ntouch, a.dbg};
       rabbit_vertex<false>(a, t, u, du, atom_child(au), &ntouch, lane);
     }
+    GCN_BEAT(a, lane, 9, 0);
   }
+  GCN_BEAT(a, lane, 10, 0);
 }
 
 __global__ void rabbit_init_kernel(const int* __restrict__ rowptr, const int* __restrict__ col, int n,
                                    unsigned long long* __restrict__ atom, unsigned* __restrict__ dest,
                                    unsigned* __restrict__ sibling, unsigned* __restrict__ agg_len,
-                                   unsigned* __restrict__ agg_child, unsigned long long* __restrict__ two_m) {
+                                   unsigned* __restrict__ agg_child, unsigned long long* __restrict__ agg_ptr,
+                                   unsigned long long* __restrict__ two_m) {
   const int v = blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= n) return;
   unsigned d = 0;
@@ -286,6 +320,7 @@ __global__ void rabbit_init_kernel(const int* __restrict__ rowptr, const int* __
   sibling[v] = kNone;
   agg_len[v] = 0;
   agg_child[v] = kNone;
+  agg_ptr[v] = 0;
   if (d) atomicAdd(two_m, (unsigned long long)d);
 }
 
@@ -342,7 +377,7 @@ hipError_t device_order_rabbit(const int* rowptr, const int* col, int n, int nnz
   GCN_R(hipMemsetAsync(cnt.p, 0, sizeof(unsigned) * kCntWords, st));     // (once, long before the first pass: see below)
   GCN_R(hipMemsetAsync(bval.p, 0, sizeof(unsigned) * (size_t)nwaves * kBigCap, st));
   rabbit_fill_kernel<<<1024, 256, 0, st>>>(bkey.p, (size_t)nwaves * kBigCap, kNone);
-  rabbit_init_kernel<<<(n + 255) / 256, 256, 0, st>>>(rowptr, col, n, atom.p, dest.p, sibling.p, agg_len.p, agg_child.p, scal.p);
+  rabbit_init_kernel<<<(n + 255) / 256, 256, 0, st>>>(rowptr, col, n, atom.p, dest.p, sibling.p, agg_len.p, agg_child.p, agg_ptr.p, scal.p);
   GCN_R(hipGetLastError());
   // processing order: ascending degree, ties by vertex id (the strict total order of order_deg, device version)
   GCN_R(device_order_deg(rowptr, col, n, nnz, /*which = out*/ 1, /*desc*/ 0, degrank.p, st));
@@ -371,6 +406,15 @@ hipError_t device_order_rabbit(const int* rowptr, const int* col, int n, int nnz
     const int retry_waves = env_int("GCN_AMD_RABBIT_RETRY_WAVES", nblocks);
     // vertices in flight see each other's merges late: keep them a small share of the list (1 in 64 or fewer)
     auto waves_for = [&](unsigned cnt_) { long long w = (long long)cnt_ / 64; if (w < 8) w = 8; if (w > nblocks) w = nblocks; return (int)w; };
+    Dev<unsigned> beat;
+    hipStream_t side = nullptr;
+    a.beat = nullptr;
+    if (env_int("GCN_AMD_RABBIT_BEAT", 0)) {             // development: watch the waves of a pass from a side stream
+      GCN_R(beat.alloc((size_t)nwaves * 4));
+      GCN_R(hipMemsetAsync(beat.p, 0, sizeof(unsigned) * (size_t)nwaves * 4, st));
+      GCN_R(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+      a.beat = beat.p;
+    }
     void* sort_tmp = nullptr;
     size_t sort_bytes = 0;
     GCN_R(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, keys.p, keys2.p, cur, nxt, n, 0, 32, st));
@@ -393,6 +437,20 @@ hipError_t device_order_rabbit(const int* rowptr, const int* col, int n, int nnz
       if (verbose) { std::fprintf(stderr, "rabbit_device: pass %lld: launching %d waves for %u vertices\n", passes + 1, launch, count); std::fflush(stderr); }
       rabbit_pass_kernel<<<launch, 64, 0, st>>>(a);
       GCN_R(hipGetLastError());
+      if (env_int("GCN_AMD_RABBIT_SLEEP", 0)) { struct timespec ts = {0, 200000000}; nanosleep(&ts, nullptr); }
+      if (side && env_int("GCN_AMD_RABBIT_BEAT", 0) == 1) {
+        std::vector<unsigned> hb((size_t)nwaves * 4);
+        for (int tick = 0; tick < 5 && hipStreamQuery(st) == hipErrorNotReady; ++tick) {
+          struct timespec ts = {1, 0};
+          nanosleep(&ts, nullptr);
+          if (hipMemcpyAsync(hb.data(), beat.p, sizeof(unsigned) * hb.size(), hipMemcpyDeviceToHost, side) != hipSuccess ||
+              hipStreamSynchronize(side) != hipSuccess) break;
+          std::fprintf(stderr, "rabbit_device: pass %lld tick %d:", passes + 1, tick);
+          for (int w = 0; w < launch; ++w) if (hb[4 * w + 1] != 10u) std::fprintf(stderr, " [w%d u=%u stage=%u x=%u]", w, hb[4 * w], hb[4 * w + 1], hb[4 * w + 2]);
+          std::fprintf(stderr, "\n");
+          std::fflush(stderr);
+        }
+      }
       unsigned h[8] = {0, 0, 0, 0, 0, 0, 0, 0}, hp[2] = {0, 0};
       GCN_R(hipMemcpyAsync(h, cnt.p, sizeof(h), hipMemcpyDeviceToHost, st));
       GCN_R(hipMemcpyAsync(hp, a.counter, sizeof(hp), hipMemcpyDeviceToHost, st));
@@ -400,7 +458,7 @@ hipError_t device_order_rabbit(const int* rowptr, const int* col, int n, int nnz
       h[1] = hp[1];
       if (verbose) {
         std::fprintf(stderr, "rabbit_device: pass %lld: %u vertices, %u to retry, %u left top-level so far; guard trips: pointer chain %u, "
-                             "child chain %u, table %u\n", passes + 1, count, h[1], h[2], h[4], h[5], h[6]);
+                             "child chain %u, table %u, index %u\n", passes + 1, count, h[1], h[2], h[4], h[5], h[6], h[7]);
         std::fflush(stderr);
       }
       count = h[1];
