@@ -74,7 +74,6 @@ int group_store() {                                                             
 bool group_ring() { static const bool v = env_on("GCN_AMD_GROUP_RING"); return v; }   // finished rows through the LDS ring (value-free pass)
 bool group_merge_tiles() { static const bool v = env_on("GCN_AMD_GROUP_MERGE_TILES"); return v; }   // all column tiles in one launch
 bool group8_enabled() { static const bool v = env_on("GCN_AMD_GROUP8"); return v; }   // k <= 32: eight 8-lane row engines per wave
-bool group16_enabled() { static const bool v = env_on("GCN_AMD_GROUP16"); return v; }   // 33 <= k <= 48: + sixteen 4-lane engines for the columns past 32
 bool group_weighted_enabled() { static const bool v = env_on("GCN_AMD_GROUP_WEIGHTED"); return v; }   // group kernel for values that do not factor
 bool quad_stream_rows() { static const bool v = env_on("GCN_AMD_QUAD_NT"); return v; }   // sliced pass with values: nt partial-row stores
 // Entries per chunk of one 16-lane group.  A block walks 16 chunks and 4 blocks are resident per CU (114 VGPRs), so the
@@ -439,7 +438,6 @@ int spmm_impl(gcn_spmm_plan* p, const int32_t* rowptr, const int32_t* col, const
     ga.ring = gcn::group_ring() ? 1 : 0;
     ga.merge_tiles = gcn::group_merge_tiles() ? 1 : 0;
     ga.narrow8 = gcn::group8_enabled() ? 1 : 0;
-    ga.narrow16 = gcn::group16_enabled() ? 1 : 0;
     if (ev0 && hipEventRecord(ev0, st) != hipSuccess) return GCN_ERR_HIP;
     if (gcn::launch_spmm_group(ga, st) != hipSuccess) return GCN_ERR_HIP;
     if (ev1 && hipEventRecord(ev1, st) != hipSuccess) return GCN_ERR_HIP;
@@ -871,8 +869,7 @@ int32_t gcn_spmm_plan_num_passes(const gcn_spmm_plan_t* p, int32_t k) {
     int kk = k, ldb = gcn::padded_ldb(p->n, k);
     if (odd_width_detour(p, k)) { kk = (k + 3) / 4 * 4; ldb = (kk + 31) / 32 * 32; }
     const bool vl = valless_pays(p, kk, ldb);
-    if (group_launch(p, vl, !vl && weighted_pass(p, kk, ldb)))   // (two launches for 33..48: 32 columns + the rest)
-      return (gcn::group8_enabled() && gcn::group16_enabled() && kk > 32 && kk <= 48 && p->group.nchunks % 128 == 0) ? 2 : 1;
+    if (group_launch(p, vl, !vl && weighted_pass(p, kk, ldb))) return 1;
   }
   const int tile = p->tile_cols ? p->tile_cols : (p->slicing.S > 0 && k > 32 ? 64 : gcn::auto_tile_cols(p->n, k));
   const int vec = gcn::pick_vec(k, tile, nullptr, nullptr, nullptr);   // 16-B aligned operands
@@ -902,18 +899,15 @@ int gcn_spmm_plan_main_kernel(const gcn_spmm_plan_t* p, int32_t k, int32_t epilo
   const int ld_eff = a.ldb > 0 ? a.ldb : a.k;
   const bool big = gcn::spmm_group_needs_big(group_table_rows(p), ld_eff);
   const char* bigs = big ? "true" : "false";
-  const bool g16 = gcn::group8_enabled() && gcn::group16_enabled() && a.k > 32 && a.k <= 48 && p->group.nchunks % 128 == 0;
   if (a.valless && group_pass(p)) {
-    if (g16)        // (the first of the two launches: 32 columns; gcn::spmm_group16_kernel takes the rest)
-      snprintf(buf, (size_t)buflen, "gcn::spmm_group8_kernel<%s, %s>", gcn::group_ring() ? "true" : "false", bigs);
-    else if (gcn::group8_enabled() && a.k <= 32 && p->group.nchunks % 64 == 0)
+    if (gcn::group8_enabled() && a.k <= 32 && p->group.nchunks % 64 == 0)
       snprintf(buf, (size_t)buflen, "gcn::spmm_group8_kernel<%s, %s>", gcn::group_ring() ? "true" : "false", bigs);
     else
       snprintf(buf, (size_t)buflen, "gcn::spmm_group%s_kernel<%d, %s>", gcn::group_ring() ? "_ring" : "", big ? 2 : gcn::group_store(), bigs);
     return GCN_OK;
   }
   if (!a.valless && weighted_pass(p, a.k, ld_eff)) {
-    if (g16 || (gcn::group8_enabled() && a.k <= 32 && p->group.nchunks % 64 == 0))
+    if (gcn::group8_enabled() && a.k <= 32 && p->group.nchunks % 64 == 0)
       snprintf(buf, (size_t)buflen, "gcn::spmm_group8_weighted_kernel<%s>", bigs);
     else
       snprintf(buf, (size_t)buflen, "gcn::spmm_group_weighted_kernel<%d, %s>", big ? 2 : gcn::group_store(), bigs);

@@ -509,8 +509,8 @@ hipError_t build_group_stream(const int* vrowptr, const int* vcol, int m, int n,
     const long long l = bounds[s + 1] - bounds[s];
     total += (l + T - 1) / T * T;
   }
-  total = (total + 128LL * T - 1) / (128LL * T) * (128LL * T);  // whole waves for every XCD (four chunks per wave in
-                                                                // spmm_group_kernel, eight in spmm_group8_kernel, sixteen in spmm_group16_kernel)
+  total = (total + 64LL * T - 1) / (64LL * T) * (64LL * T);     // whole waves for every XCD (four chunks per wave in
+                                                                // spmm_group_kernel, eight in spmm_group8_kernel)
   if (total >= (1LL << 31)) { cleanup(true); return hipErrorInvalidValue; }
   pad_before[S] = (int)(total - bounds[S]);
   const int nchunks = (int)(total / T);

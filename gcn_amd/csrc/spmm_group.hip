@@ -269,9 +269,7 @@ template <bool RING, bool VALS, bool BIG>
 __device__ __forceinline__ void
 group8_walk(const unsigned short* __restrict__ stream, const float* __restrict__ vals, const int2* __restrict__ chunk_meta,
             const float* __restrict__ Bp, float* __restrict__ Cv, float* __restrict__ P,
-            int nchunks, int T, int k, int ldb, int stream_nt, const int* __restrict__ dyn, int col0 = 0, int kw = 32) {
-  // (col0, kw): the pass covers columns [col0, col0 + min(kw, 32)) of the k-wide result — the whole of it for k <= 32,
-  // the first 32 of a 33..48-wide one whose remaining columns the sixteen-engine kernel below takes
+            int nchunks, int T, int k, int ldb, int stream_nt, const int* __restrict__ dyn) {
   if (dyn) { if (dyn[0] == 0) return; nchunks = dyn[1]; }      // (as group_walk)
   const int lane = threadIdx.x & 63;
   const int wib  = threadIdx.x >> 6;
@@ -283,10 +281,10 @@ group8_walk(const unsigned short* __restrict__ stream, const float* __restrict__
   if (c_in >= per_xcd) return;                                  // (whole wave: per_xcd % 8 == 0)
   const int c = (int)(blockIdx.x & 7) * per_xcd + c_in + g;     // this group's chunk
 
-  const int fcol = col0 + f * 4;
-  const bool fok = f * 4 < kw && fcol < k;
+  const int fcol = f * 4;
+  const bool fok = fcol < k;
   const unsigned row_bytes = (unsigned)ldb * 4u;
-  const unsigned foff = (unsigned)(fok ? fcol : col0) * 4u;
+  const unsigned foff = (unsigned)(fok ? fcol : 0) * 4u;
   const char* Bb = reinterpret_cast<const char*>(Bp);
   const size_t kk = (size_t)k;
 
@@ -447,8 +445,8 @@ template <bool RING, bool BIG>
 __global__ void __launch_bounds__(256)
 spmm_group8_kernel(const unsigned short* __restrict__ stream, const int2* __restrict__ chunk_meta,
                    const float* __restrict__ Bp, float* __restrict__ Cv, float* __restrict__ P,
-                   int nchunks, int T, int k, int ldb, int stream_nt, const int* __restrict__ dyn, int col0, int kw) {
-  group8_walk<RING, false, BIG>(stream, nullptr, chunk_meta, Bp, Cv, P, nchunks, T, k, ldb, stream_nt, dyn, col0, kw);
+                   int nchunks, int T, int k, int ldb, int stream_nt, const int* __restrict__ dyn) {
+  group8_walk<RING, false, BIG>(stream, nullptr, chunk_meta, Bp, Cv, P, nchunks, T, k, ldb, stream_nt, dyn);
 }
 
 // ... and with the values beside the stream (matrices whose values do not factor); no ring: 138 VGPRs without
@@ -456,146 +454,8 @@ template <bool BIG>
 __global__ void __launch_bounds__(256)
 spmm_group8_weighted_kernel(const unsigned short* __restrict__ stream, const float* __restrict__ vals,
                             const int2* __restrict__ chunk_meta, const float* __restrict__ Bp, float* __restrict__ Cv,
-                            float* __restrict__ P, int nchunks, int T, int k, int ldb, int stream_nt, const int* __restrict__ dyn,
-                            int col0, int kw) {
-  group8_walk<false, true, BIG>(stream, vals, chunk_meta, Bp, Cv, P, nchunks, T, k, ldb, stream_nt, dyn, col0, kw);
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// <= 16 columns: SIXTEEN independent 4-lane row engines per wave (lane = g*4 + f, f = which float4 of the 16-column
-// tile): one gather instruction fetches sixteen feature-row pieces of 64 bytes.  It exists for the widths between the
-// tiles — k = 33..48 (the class counts of real GCNs: 41, 47; hidden sizes 40, 48) rode a 64-column pass with a quarter
-// to a half of its lanes idle; now the eight-engine kernel takes the first 32 columns and this one the rest, both on
-// the same stream, chunk metadata, partial slab and fix list (every piece lands at its own columns).  A 4-lane group is
-// a DPP quad, so the broadcast of an entry to its group is one quad_perm.  Lane f of a group reads its entries of a
-// run's sixteen 4-entry blocks as four 8-byte words (word 4j + f holds blocks j, j+4, j+8, j+12: group_phys).
-// Sixteen gathers (four blocks) are in flight together.  No LDS ring: a 64-byte row piece per store.
-template <int UU>
-__device__ __forceinline__ int quad_bcast(int v) {               // value held by lane UU of this lane's quad
-  return __builtin_amdgcn_mov_dpp(v, UU * 0x55, 0xf, 0xf, true);
-}
-
-template <bool VALS, bool BIG>
-__device__ __forceinline__ void
-group16_walk(const unsigned short* __restrict__ stream, const float* __restrict__ vals, const int2* __restrict__ chunk_meta,
-             const float* __restrict__ Bp, float* __restrict__ Cv, float* __restrict__ P,
-             int nchunks, int T, int k, int col0, int ldb, int stream_nt, const int* __restrict__ dyn) {
-  if (dyn) { if (dyn[0] == 0) return; nchunks = dyn[1]; }
-  const int lane = threadIdx.x & 63;
-  const int wib  = threadIdx.x >> 6;
-  const int g    = lane >> 2;
-  const int f    = lane & 3;
-  const int per_xcd = nchunks >> 3;
-  const int c_in = ((int)(blockIdx.x >> 3) * 4 + wib) * 16;
-  if (c_in >= per_xcd) return;                                  // (whole wave: per_xcd % 16 == 0)
-  const int c = (int)(blockIdx.x & 7) * per_xcd + c_in + g;     // this group's chunk
-
-  const int fcol = col0 + f * 4;
-  const bool fok = fcol < k;
-  const unsigned row_bytes = (unsigned)ldb * 4u;
-  const unsigned foff = (unsigned)(fok ? fcol : col0) * 4u;
-  const char* Bb = reinterpret_cast<const char*>(Bp);
-  const size_t kk = (size_t)k;
-
-  const int2 meta = chunk_meta[c];
-  const int vrow = meta.x >> 1;
-  const bool head = meta.x & 1;
-  const int base = BIG ? 0 : meta.y;
-  if constexpr (BIG) Bb += (size_t)meta.y * (size_t)row_bytes;
-  float* ptr  = head ? P + (size_t)(2 * c) * kk + fcol : Cv + (size_t)vrow * kk + fcol;
-  float* nptr = Cv + (size_t)(vrow + 1) * kk + fcol;
-  bool first = true;
-
-  typedef unsigned int u32x2_q __attribute__((ext_vector_type(2)));
-  const u32x2_q* __restrict__ sp = reinterpret_cast<const u32x2_q*>(stream + (size_t)c * T) + f;
-  const f32x4* __restrict__ vp = VALS ? reinterpret_cast<const f32x4*>(vals + (size_t)c * T) + f : nullptr;
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  u32x2_q w[4], w_nx[4];
-  f32x4 v[4], v_nx[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    w[j] = stream_nt ? __builtin_nontemporal_load(sp + 4 * j) : sp[4 * j];
-    w_nx[j] = w[j];
-    v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if constexpr (VALS) v[j] = stream_nt ? __builtin_nontemporal_load(vp + 4 * j) : vp[4 * j];
-    v_nx[j] = v[j];
-  }
-  unsigned fl3 = 0;
-#pragma unroll 1
-  for (int d = 0; d < T / 16; ++d) {                            // four consecutive 4-entry blocks per turn
-    const int q = d & 3;                                        // turn q of a run: blocks 4q .. 4q+3 = component q of words 0 .. 3
-    if (q == 0 && d + 4 < T / 16) {                             // the next run, a whole run ahead of its use
-      const int nx = (d / 4 + 1) * 16;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        w_nx[j] = stream_nt ? __builtin_nontemporal_load(sp + nx + 4 * j) : sp[nx + 4 * j];
-        if constexpr (VALS) v_nx[j] = stream_nt ? __builtin_nontemporal_load(vp + nx + 4 * j) : vp[nx + 4 * j];
-      }
-    }
-    // this lane's entries of the turn's four blocks, in stream order: block 4q + j is component q of word j
-    unsigned e[4];
-    int ro[4], vb[4];
-    unsigned fl[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      e[j] = ((q & 2 ? w[j].y : w[j].x) >> (16 * (q & 1))) & 0xFFFFu;
-      ro[j] = (int)(__umul24((e[j] & 0x7FFFu) + (unsigned)base, row_bytes));
-      fl[j] = e[j] >> 15;
-      vb[j] = 0;
-      if constexpr (VALS) vb[j] = __builtin_bit_cast(int, q == 0 ? v[j].x : q == 1 ? v[j].y : q == 2 ? v[j].z : v[j].w);
-    }
-    if (q == 3) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { w[j] = w_nx[j]; v[j] = v_nx[j]; }
-    }
-    (void)e;
-    float4 b[16];
-#define GCN_G16_GATHER(J, UU) \
-    b[(J) * 4 + (UU)] = *reinterpret_cast<const float4*>(Bb + (size_t)((unsigned)quad_bcast<UU>(ro[J]) + foff));
-#define GCN_G16_ALLJ(M) M(0, 0) M(0, 1) M(0, 2) M(0, 3) M(1, 0) M(1, 1) M(1, 2) M(1, 3) M(2, 0) M(2, 1) M(2, 2) M(2, 3) M(3, 0) M(3, 1) M(3, 2) M(3, 3)
-    GCN_G16_ALLJ(GCN_G16_GATHER)
-#undef GCN_G16_GATHER
-    unsigned long long ends[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) ends[j] = __ballot(fl[j] != 0);
-#define GCN_G16_ADD(J, UU)                                                                          \
-    if constexpr (VALS) {                                                                           \
-      const float vu = __builtin_bit_cast(float, quad_bcast<UU>(vb[J]));                            \
-      acc.x = fmaf(vu, b[(J) * 4 + (UU)].x, acc.x); acc.y = fmaf(vu, b[(J) * 4 + (UU)].y, acc.y);   \
-      acc.z = fmaf(vu, b[(J) * 4 + (UU)].z, acc.z); acc.w = fmaf(vu, b[(J) * 4 + (UU)].w, acc.w);   \
-    } else { acc.x += b[(J) * 4 + (UU)].x; acc.y += b[(J) * 4 + (UU)].y; acc.z += b[(J) * 4 + (UU)].z; acc.w += b[(J) * 4 + (UU)].w; }
-    if ((ends[0] | ends[1] | ends[2] | ends[3]) == 0ull) {
-      GCN_G16_ALLJ(GCN_G16_ADD)
-    } else {
-#define GCN_G16_STEP(J, UU)                                                                         \
-      GCN_G16_ADD(J, UU)                                                                            \
-      if (ends[J] & (0x1111111111111111ull << (UU))) {          /* some group ends a row here */    \
-        if (quad_bcast<UU>((int)fl[J])) {                                                           \
-          if (fok) store_row_piece<2>(ptr, acc);                                                    \
-          acc = make_float4(0.f, 0.f, 0.f, 0.f);                                                    \
-          ptr = nptr; nptr += kk; first = false;                                                    \
-        }                                                                                           \
-      }
-      GCN_G16_ALLJ(GCN_G16_STEP)
-#undef GCN_G16_STEP
-    }
-#undef GCN_G16_ADD
-#undef GCN_G16_ALLJ
-    fl3 = fl[3];
-  }
-  // the row piece that sticks out of the chunk's end (the chunk's last entry — entry 3 of its last block — did not end its row)
-  if (!quad_bcast<3>((int)fl3)) {
-    float* dst = (head && first) ? ptr : P + (size_t)(2 * c + 1) * kk + fcol;
-    if (fok) store_row_piece<2>(dst, acc);
-  }
-}
-
-template <bool VALS, bool BIG>
-__global__ void __launch_bounds__(256)
-spmm_group16_kernel(const unsigned short* __restrict__ stream, const float* __restrict__ vals, const int2* __restrict__ chunk_meta,
-                    const float* __restrict__ Bp, float* __restrict__ Cv, float* __restrict__ P,
-                    int nchunks, int T, int k, int col0, int ldb, int stream_nt, const int* __restrict__ dyn) {
-  group16_walk<VALS, BIG>(stream, vals, chunk_meta, Bp, Cv, P, nchunks, T, k, col0, ldb, stream_nt, dyn);
+                            float* __restrict__ P, int nchunks, int T, int k, int ldb, int stream_nt, const int* __restrict__ dyn) {
+  group8_walk<false, true, BIG>(stream, vals, chunk_meta, Bp, Cv, P, nchunks, T, k, ldb, stream_nt, dyn);
 }
 
 // 32-bit byte offsets (entry + slice base) * row_bytes reach every row of the sliced copy?  (__umul24: both factors
@@ -620,26 +480,7 @@ bool spmm_group8_applies(const GroupArgs& a) {
   return a.narrow8 && a.k <= 32 && a.k % 4 == 0 && a.nchunks % 64 == 0;
 }
 
-// 33 <= k <= 48, whole waves of sixteen chunks per XCD: 32 columns on the eight-engine kernel, the rest on the sixteen-engine one
-bool spmm_group16_applies(const GroupArgs& a) {
-  return a.narrow8 && a.narrow16 && a.k > 32 && a.k <= 48 && a.k % 4 == 0 && a.nchunks % 128 == 0;
-}
-
 namespace {
-
-template <bool BIG>
-hipError_t launch_group8_16_t(const GroupArgs& a, int ldb, hipStream_t s) {
-  const int per_xcd = a.nchunks / 8;
-  const int stream_nt = (size_t)a.nchunks * (size_t)a.T * (a.vals ? 6u : 2u) > ((size_t)64 << 20) ? 1 : 0;
-  const int nb8 = 8 * ((per_xcd + 31) / 32), nb16 = 8 * ((per_xcd + 63) / 64);
-  const int2* meta = reinterpret_cast<const int2*>(a.chunk_meta);
-  if (a.vals)      spmm_group8_weighted_kernel<BIG><<<dim3(nb8), dim3(256), 0, s>>>(a.stream, a.vals, meta, a.Bp, a.Cv, a.P, a.nchunks, a.T, a.k, ldb, stream_nt, a.dyn, 0, 32);
-  else if (a.ring) spmm_group8_kernel<true, BIG><<<dim3(nb8), dim3(256), 0, s>>>(a.stream, meta, a.Bp, a.Cv, a.P, a.nchunks, a.T, a.k, ldb, stream_nt, a.dyn, 0, 32);
-  else             spmm_group8_kernel<false, BIG><<<dim3(nb8), dim3(256), 0, s>>>(a.stream, meta, a.Bp, a.Cv, a.P, a.nchunks, a.T, a.k, ldb, stream_nt, a.dyn, 0, 32);
-  if (a.vals) spmm_group16_kernel<true, BIG><<<dim3(nb16), dim3(256), 0, s>>>(a.stream, a.vals, meta, a.Bp, a.Cv, a.P, a.nchunks, a.T, a.k, 32, ldb, stream_nt, a.dyn);
-  else        spmm_group16_kernel<false, BIG><<<dim3(nb16), dim3(256), 0, s>>>(a.stream, nullptr, meta, a.Bp, a.Cv, a.P, a.nchunks, a.T, a.k, 32, ldb, stream_nt, a.dyn);
-  return hipGetLastError();
-}
 
 template <bool BIG>
 hipError_t launch_group8_t(const GroupArgs& a, int ldb, hipStream_t s) {
@@ -647,9 +488,9 @@ hipError_t launch_group8_t(const GroupArgs& a, int ldb, hipStream_t s) {
   const int stream_nt8 = (size_t)a.nchunks * (size_t)a.T * (a.vals ? 6u : 2u) > ((size_t)64 << 20) ? 1 : 0;
   const int nb8 = 8 * ((per_xcd + 31) / 32);
   const int2* meta = reinterpret_cast<const int2*>(a.chunk_meta);
-  if (a.vals)      spmm_group8_weighted_kernel<BIG><<<dim3(nb8), dim3(256), 0, s>>>(a.stream, a.vals, meta, a.Bp, a.Cv, a.P, a.nchunks, a.T, a.k, ldb, stream_nt8, a.dyn, 0, 32);
-  else if (a.ring) spmm_group8_kernel<true, BIG><<<dim3(nb8), dim3(256), 0, s>>>(a.stream, meta, a.Bp, a.Cv, a.P, a.nchunks, a.T, a.k, ldb, stream_nt8, a.dyn, 0, 32);
-  else             spmm_group8_kernel<false, BIG><<<dim3(nb8), dim3(256), 0, s>>>(a.stream, meta, a.Bp, a.Cv, a.P, a.nchunks, a.T, a.k, ldb, stream_nt8, a.dyn, 0, 32);
+  if (a.vals)      spmm_group8_weighted_kernel<BIG><<<dim3(nb8), dim3(256), 0, s>>>(a.stream, a.vals, meta, a.Bp, a.Cv, a.P, a.nchunks, a.T, a.k, ldb, stream_nt8, a.dyn);
+  else if (a.ring) spmm_group8_kernel<true, BIG><<<dim3(nb8), dim3(256), 0, s>>>(a.stream, meta, a.Bp, a.Cv, a.P, a.nchunks, a.T, a.k, ldb, stream_nt8, a.dyn);
+  else             spmm_group8_kernel<false, BIG><<<dim3(nb8), dim3(256), 0, s>>>(a.stream, meta, a.Bp, a.Cv, a.P, a.nchunks, a.T, a.k, ldb, stream_nt8, a.dyn);
   return hipGetLastError();
 }
 
@@ -687,7 +528,6 @@ hipError_t launch_spmm_group(const GroupArgs& a, hipStream_t s) {
   const bool big = spmm_group_needs_big(a.table_rows, ldb);
   if (big && ldb * 4 >= (1 << 17)) return hipErrorInvalidValue;
   if (spmm_group8_applies(a)) return big ? launch_group8_t<true>(a, ldb, s) : launch_group8_t<false>(a, ldb, s);
-  if (spmm_group16_applies(a)) return big ? launch_group8_16_t<true>(a, ldb, s) : launch_group8_16_t<false>(a, ldb, s);
   if (big) return launch_group_tp<2, true>(a, ldb, s);               // (the store policy is a tuning knob: BIG keeps the default)
   if (a.store_policy == 1) return launch_group_tp<1, false>(a, ldb, s);
   if (a.store_policy == 2) return launch_group_tp<2, false>(a, ldb, s);

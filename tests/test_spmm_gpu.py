@@ -538,48 +538,6 @@ def test_dropin_flexspmm_reads_its_launch_parameters_on_the_device():
     assert bool((C == 3.0).all())
 
 
-def test_widths_between_the_tiles_take_a_32_column_and_a_16_column_pass():
-    """k = 33..48 (GCN class counts 41, 47; hidden sizes 40, 48): the eight-engine kernel takes the first 32 columns and
-    the sixteen-engine kernel (spmm_group16_kernel: sixteen 4-lane row engines per wave) the rest, instead of one
-    64-column pass with up to half of its lanes idle.  Value-free and weighted plans, several slice counts, epilogue,
-    odd widths through the k' detour, against the fp64 oracle; 52..60 keep the 64-column pass."""
-    n = 17000
-    rowptr, col, val = sym_norm_graph(n, 1200000, seed=23)
-    rng = np.random.default_rng(11)
-    d = _dev()
-    val_w = (val * (1.0 + 0.5 * rng.random(len(val)))).astype(np.float32)        # values that do not factor
-    for weighted, v in ((False, val), (True, val_w)):
-        for S in ("auto", 3, 8):
-            adj = _adj(rowptr, col, v, n, n) if S == "auto" else _adj(rowptr, col, v, n, n, slices=S)
-            assert adj.has_value_factors == (not weighted)
-            for k in (36, 40, 44, 48, 41, 47, 33):
-                name = adj.main_kernel(k)
-                assert name.startswith("gcn::spmm_group8_weighted_kernel<" if weighted else "gcn::spmm_group8_kernel<"), (k, name)
-                assert adj.num_passes(k) == 2
-                B = rng.standard_normal((n, k)).astype(np.float32)
-                Bd = torch.from_numpy(B).to(d)
-                ref = oracle_spmm(rowptr, col, v, B)
-                C = adj.matmul_raw(Bd)
-                assert rel_err(C.cpu().numpy(), ref) <= TOL, (weighted, S, k)
-                assert torch.equal(C, adj.matmul_raw(Bd))                        # reproducible
-                if k in (36, 41, 48):
-                    bias = rng.standard_normal(k).astype(np.float32)
-                    Ce = adj.matmul_raw(Bd, bias=torch.from_numpy(bias).to(d), relu=True).cpu().numpy()
-                    assert rel_err(Ce, np.maximum(ref + bias, 0)) <= TOL, (weighted, S, k)
-            assert adj.num_passes(52) == 1 and not adj.main_kernel(52).startswith("gcn::spmm_group8")
-    # non-finite values stay in the rows that reference them (every pass masks by row, not by block)
-    adj = _adj(rowptr, col, val, n, n)
-    B = rng.standard_normal((n, 44)).astype(np.float32)
-    B[5, 40] = np.inf; B[9, 3] = np.nan
-    C = adj.matmul_raw(torch.from_numpy(B).to(d)).cpu().numpy()
-    A = sp.csr_matrix((val, col, rowptr), shape=(n, n))
-    touched = np.unique(np.concatenate([A[:, 5].nonzero()[0], A[:, 9].nonzero()[0]]))
-    clean = np.setdiff1d(np.arange(n), touched)
-    assert np.isfinite(C[clean]).all()
-    Bf = B.copy(); Bf[5, 40] = 0; Bf[9, 3] = 0
-    assert rel_err(C[clean], oracle_spmm(rowptr, col, val, Bf)[clean]) <= TOL
-
-
 def test_prelaid_chain_needs_no_feature_copy_and_writes_the_next_layers_input():
     """gcn_spmm_csr_f32_prelaid: B handed over in the plan's slice-by-slice, column-scaled layout B' (no per-call copy),
     the result written straight into a consumer's B' (gapped rows, times the consumer's column factor).  A square
@@ -988,7 +946,7 @@ def test_narrow_widths_on_the_eight_engine_kernel(S):
         assert torch.equal(C, adj.matmul_raw(Bd))
         Ce = adj.matmul_raw(Bd, bias=torch.from_numpy(bias).to(_dev()), relu=True).cpu().numpy()
         assert rel_err(Ce, np.maximum(Cref + bias, 0)) <= TOL, k
-    assert adj.main_kernel(36).startswith("gcn::spmm_group8_kernel<")          # 32 columns + a sixteen-engine pass for the rest (r03)
+    assert adj.main_kernel(36).startswith("gcn::spmm_group_ring_kernel<")
     assert not adj.main_kernel(8).startswith("gcn::spmm_group")
 
 
