@@ -33,6 +33,8 @@ its shard to each peer and receives theirs in ONE grouped batch of point-to-poin
 link once, where a ring all-gather forwards every shard over world-1 hops.  Both forms fill
 the same buffer with the same bytes.
 """
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
