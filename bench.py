@@ -382,7 +382,8 @@ def main():
     gathered = local_nnz * cols_per_launch * 4            # feature-row bytes the kernel pulls through L2 -> CU per launch
     kname = local_adj.main_kernel(kp)
     full_size = args.scale == 1.0 and (args.graph != "rmat24" or args.rmat_scale == 24)
-    pmc = pmc_traffic(args.graph, k, order, passes, kname.split("<")[0]) if not sharded and full_size else None
+    pmc = pmc_traffic(args.graph, k, order, passes, kname.split("<")[0]) if (not sharded and full_size and
+                                                                             args.graph_device == "gpu") else None
     traffic, pmc_hit, pmc_src = pmc if pmc else (None, None, None)
     n_cols = n if not sharded else shard.world * shard.max_rows
     compulsory = local_nnz * 8 + (local_m + 1) * 4 + n_cols * kp * 4 + local_m * kp * 4
