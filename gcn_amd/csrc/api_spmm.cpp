@@ -380,7 +380,6 @@ int spmm_impl(gcn_spmm_plan* p, const int32_t* rowptr, const int32_t* col, const
   if (p->prof.armed()) { const auto pr = p->prof.next(); ev0 = pr.first; ev1 = pr.second; }
   a.blocks_per_cu = p->blocks_per_cu;
   a.gather_width = p->gather_width;
-  a.hub_cols = p->hub_cols;
   gcn::Panels& pn = p->panels;
   if (pn.R > 0 && p->nnz > 0 && k > 32) {
     // A = A_in + A_out: the staged part from LDS (raw sums into C), then the rest accumulated by the

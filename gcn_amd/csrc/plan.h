@@ -152,7 +152,6 @@ struct gcn_spmm_plan {
   gcn::EventPairs prof;
   int tile_cols = 0;                                // 0 = auto
   int gather_width = 0;                             // non-zeros per gather instruction of the 64-column kernel: 0 auto, 1, 4
-  int hub_cols = [] { const char* e = std::getenv("GCN_AMD_HUB_COLS"); return e ? std::atoi(e) : 0; }();   // experiment (spmm_kernels.h)
   int blocks_per_cu = 32;                           // grid size: blocks of 4 waves per CU (oversubscribed on purpose)
   gcn::Slicing slicing;
   bool slices_auto = false;                         // the slice count was chosen by auto_slices (enable_slicing(-1))

@@ -437,7 +437,6 @@ hipError_t device_order_rabbit(const int* rowptr, const int* col, int n, int nnz
       if (verbose) { std::fprintf(stderr, "rabbit_device: pass %lld: launching %d waves for %u vertices\n", passes + 1, launch, count); std::fflush(stderr); }
       rabbit_pass_kernel<<<launch, 64, 0, st>>>(a);
       GCN_R(hipGetLastError());
-      if (env_int("GCN_AMD_RABBIT_SLEEP", 0)) { struct timespec ts = {0, 200000000}; nanosleep(&ts, nullptr); }
       if (side && env_int("GCN_AMD_RABBIT_BEAT", 0) == 1) {
         std::vector<unsigned> hb((size_t)nwaves * 4);
         for (int tick = 0; tick < 5 && hipStreamQuery(st) == hipErrorNotReady; ++tick) {

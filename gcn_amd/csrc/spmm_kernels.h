@@ -35,7 +35,6 @@ struct SpmmArgs {
   int valless = 0;         // 1: ignore val (every entry counts 1): the caller pre-scaled B and post-scales the rows
   int stream_rows = 0;     // 1: finished rows are written with non-temporal stores (partial rows of a sliced pass: read back
                            // only by the slice reduction; spmm_quad_kernel)
-  int hub_cols = 0;        // > 0 (widest tile, no epilogue): columns below it are gathered with ordinary loads, the rest streamed
   int gather_width = 0;    // 64-column tile: non-zeros per gather instruction, 0 auto (4 when eligible), 1, 4
   int blocks_per_cu = 32;  // grid size in 256-thread blocks per CU (1..64).  Up to 8 (4 for the 108-VGPR
                            // quad kernel) are resident; more = later blocks start as earlier ones end, i.e.

@@ -64,15 +64,6 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // goes into the instruction's SGPR offset (col * row_bytes, 32-bit) and the lane part into a
 // constant VGPR offset, so a gather costs v_readlane + s_mul + buffer_load and no 64-bit vector
 // address arithmetic (requires n*k*4 < 4 GiB); otherwise flat 64-bit addressing.
-// streaming (non-temporal) form of load_vec: the line is not kept in L2 ahead of normally loaded ones
-template <int VEC>
-__device__ __forceinline__ void load_vec_nt(const float* p, float (&out)[VEC]) {
-  typedef float vnt __attribute__((ext_vector_type(VEC)));
-  const vnt v = __builtin_nontemporal_load(reinterpret_cast<const vnt*>(p));
-#pragma unroll
-  for (int i = 0; i < VEC; ++i) out[i] = v[i];
-}
-
 template <int VEC, bool BUF>
 __device__ __forceinline__ void gather_row(const float* __restrict__ Bl, __amdgpu_buffer_rsrc_t rsrc,
                                            int voff, int cu, size_t k, unsigned row_bytes,
@@ -111,18 +102,14 @@ __global__ void plan_chunk_rows_kernel(const int* __restrict__ rowptr, int m, in
 // ---------------------------------------------------------------------------
 // main kernel
 // ---------------------------------------------------------------------------
-// HUB: columns below hub_cols are "hub" columns (a degree-descending numbering puts the heavy columns first): their
-// feature rows are gathered with ordinary loads and stay in L2, every other row with streaming loads that do not
-// displace them — cache blocking for skewed graphs whose table is far larger than the caches, without slicing.
-template <int VEC, int U, bool EPI, bool BUF, bool HUB = false>
+template <int VEC, int U, bool EPI, bool BUF>
 __global__ void __launch_bounds__(256)
 spmm_chunk_kernel(const int* __restrict__ g_rowptr, const int* __restrict__ g_col,
                   const float* __restrict__ g_val, const float* __restrict__ g_B,
                   float* __restrict__ g_C, float* __restrict__ g_P,
                   const int* __restrict__ g_chunk_row, const float* __restrict__ g_bias,
                   const int* __restrict__ g_nnz_dev,
-                  int relu, int nchunks, int T, int m, int nnz, int kk, int col_tile, int accumulate, int ldb,
-                  int hub_cols = 0) {
+                  int relu, int nchunks, int T, int m, int nnz, int kk, int col_tile, int accumulate, int ldb) {
   // drop-in (flexspmm) mode: the host does not know nnz; it lives in rowptr[m] and
   // the values follow the column indices in one buffer (api.cpp, csr2tile layout)
   if (g_nnz_dev) {
@@ -233,12 +220,7 @@ spmm_chunk_kernel(const int* __restrict__ g_rowptr, const int* __restrict__ g_co
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const int cu = __builtin_amdgcn_readlane(cj, j + u);
-          if constexpr (HUB) {
-            if (cu < hub_cols) load_vec<VEC>(Bl + (size_t)cu * ldB, b[u]);
-            else               load_vec_nt<VEC>(Bl + (size_t)cu * ldB, b[u]);
-          } else {
-            gather_row<VEC, BUF>(Bl, rsrc, voff, cu, ldB, row_bytes, b[u]);
-          }
+          gather_row<VEC, BUF>(Bl, rsrc, voff, cu, ldB, row_bytes, b[u]);
         }
         if (row_end - pos >= U || row_end < 0) {
           // fast path: the current row does not end strictly inside this batch
@@ -380,10 +362,6 @@ static hipError_t launch_main(const SpmmArgs& a, int nblocks, bool epi, hipStrea
   // buffer addressing needs every byte offset into B to fit 32 bits
   const bool buf = VEC == 1 && (unsigned long long)a.n * (unsigned long long)ldb * 4ull < 0xFFFFFFF0ull;
   for (int t = 0; t < tiles; ++t) {
-    if (a.hub_cols > 0 && !epi) {          // hub columns cached, the rest streamed (flat addressing)
-      spmm_chunk_kernel<VEC, U, false, false, true><<<grid, block, 0, s>>>(GCN_MAIN_ARGS, a.hub_cols);
-      continue;
-    }
     if constexpr (VEC == 1) {
       if (buf) {
         if (epi) spmm_chunk_kernel<VEC, U, true, true><<<grid, block, 0, s>>>(GCN_MAIN_ARGS);

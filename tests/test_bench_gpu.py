@@ -94,3 +94,32 @@ def test_two_rank_rehearsal_on_one_gpu_exchanges_and_checks_on_every_rank():
         d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
         assert d["n_gpus"] == 2 and d["check"]["passed"] and d["config"]["ranks_seen"] == 2
         assert ("isend" in d["config"]["collective"]) == (exchange == "direct")
+
+
+def test_config5_gorder_leg_loads_an_offline_rank_for_the_cpu_generated_graph(tmp_path):
+    """BASELINE config 5's Gorder leg at full size uses a rank computed once, off-line (tools/gorder_rmat24.py: the host
+    Gorder needs two hours at scale 24).  The same mechanism at scale 12: the tool writes rank + hashes, bench.py
+    regenerates the CPU-generator graph, checks the hashes, loads the rank and says so; a tampered rank is refused."""
+    import numpy as np
+    rank_f = os.path.join(ROOT, "artifacts", "gorder_rmat12_rank.npy")
+    meta_f = os.path.join(ROOT, "profiles", "r03_gorder_rmat12.json")
+    try:
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gorder_rmat24.py"), "--scale", "12"], cwd=ROOT,
+                             capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0 and os.path.exists(rank_f) and os.path.exists(meta_f), out.stderr[-1500:]
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--graph", "rmat24", "--rmat-scale", "12", "--graph-device", "cpu",
+               "--order", "gorder", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+        out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-1500:]
+        d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+        assert d["check"]["passed"] and d["config"]["order"] == "gorder" and "CPU generator" in d["config"]["workload"]
+        assert "off-line" in d["config"]["ordering_ran_on"] and d["config"]["ordering_seconds"] == json.load(open(meta_f))["gorder_host_seconds"]
+        r = np.load(rank_f)
+        r[[0, 1]] = r[[1, 0]]
+        np.save(rank_f, r)                                           # not the rank the hashes were taken of
+        out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+        assert out.returncode != 0 and "hash mismatch" in out.stderr
+    finally:
+        for f in (rank_f, meta_f):
+            if os.path.exists(f):
+                os.remove(f)

@@ -1,9 +1,12 @@
 #!/usr/bin/env python3
 """tools/hub_probe.py — does a hub / cold split of the feature-row gathers pay on a skewed graph whose table is far
-larger than the caches?    The graph is renumbered by degree (hubs first); for every tile width
-the unsliced kernel runs with columns < H gathered by ordinary loads (they stay in L2) and the rest by streaming
-loads (GCN_AMD_HUB_COLS, spmm_chunk_kernel<.., HUB>), H = 0 being today's kernel.  Development aid.
-    python tools/hub_probe.py --scale 24 --k 512 --tiles 256,64 --hubs 0,2048,4096,16384"""
+larger than the caches?  (it loses both ways.)  The graph is renumbered by degree
+(hubs first).  `--split H,...`: A = A_hub (columns < H, compact table of H rows) + A_cold as two SpMMs through the public
+API.  Without --split: the cache-policy variant — columns < H gathered by ordinary loads, the rest by streaming loads —
+which needs the `HUB` instantiation of spmm_chunk_kernel and the GCN_AMD_HUB_COLS knob that lived in the tree from
+9c723bb to the commit that removed them again (profiles/r03c_hub_cache_policy_probe_rmat24.log is its output); with
+today's library that sweep times the plain kernel for every H.  Development aid.
+    python tools/hub_probe.py --scale 24 --k 512 --split 8192,16384,65536"""
 import argparse
 import os
 import sys
