@@ -166,6 +166,12 @@ class RowShardedAdjacency:
             lay = self.local.prelaid_layout(plane_cols) if (self._factors is not None and hasattr(self.local, "prelaid_layout")) else None
             ok = (lay is not None and lay["slices"] == self.world * self.slices_per_rank and lay["slice_cols"] == self.slice_cols
                   and lay["ld"] == plane_cols)
+            # the ranks must AGREE: a rank whose block falls on the other side of a rule (non-zeros per column, table
+            # sizes) would size its exchange buffers differently and the collective would hang.  One MIN over the ranks.
+            if self.world > 1 and dist.is_available() and dist.is_initialized() and dist.get_world_size() == self.world:
+                flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                ok = bool(int(flag.item()))
             if not ok:
                 if prelaid is True:
                     raise _lib.GcnAmdError(f"prelaid=True: the local operator does not offer the layout (got {lay})")
