@@ -687,6 +687,20 @@ int gcn_spmm_plan_enable_slicing(gcn_spmm_plan_t* p, const int32_t* rowptr, cons
       p->factors.u_col = p->factors.u_row;
     }
   }
+  // ... or depend on the row only / on the column only (r03): an unweighted adjacency (all ones), the row-normalised
+  // D^-1 (A+I) of Kipf's pygcn, and its transpose (what the backward pass multiplies with) factor as u_row[r] * 1 and
+  // 1 * u_col[c]; any shape.  Same 4-ulp check of every entry.
+  if (gcn::valless_enabled() && !p->factors.ready() && (!autom || gcn::auto_slices(p->m, p->n, p->nnz, false) > 1)) {
+    for (int mode = 1; mode <= 2 && !p->factors.ready(); ++mode) {
+      gcn::Factors f;
+      int ok = 0;
+      if (f.u_row.alloc((size_t)p->m) == hipSuccess && f.u_col_own.alloc((size_t)p->n) == hipSuccess &&
+          gcn::detect_constant_values(rowptr, col, val, p->m, p->n, p->nnz, mode, f.u_row, f.u_col_own, &ok, st) == hipSuccess && ok) {
+        f.u_col = f.u_col_own;
+        p->factors = std::move(f);
+      }
+    }
+  }
   if (autom) slices = gcn::auto_slices(p->m, p->n, p->nnz, group_plan(p));
   if (slices <= 1) return GCN_OK;
   if ((long long)slices * p->m + 1 >= (1LL << 31)) return GCN_ERR_INVALID_ARG;

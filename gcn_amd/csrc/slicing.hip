@@ -26,6 +26,9 @@
 
 namespace gcn {
 
+hipError_t verify_value_factors(const int* rowptr, const int* col, const float* val, const float* u_row,
+                                const float* u_col, int m, int* ok_host, hipStream_t st);
+
 // cnt[s*m + r] = number of non-zeros of row r with column in [s*w, (s+1)*w);  *unsorted is set
 // when a row's columns are not ascending.  One thread per (row, slice boundary).
 __global__ void slice_count_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
@@ -636,6 +639,42 @@ hipError_t detect_rank1_values(const int* rowptr, const int* col, const float* v
   (void)hipFree(fail);
   if (e == hipSuccess) *ok_host = h ? 0 : 1;
   return e;
+}
+
+// ---- values that depend on the row only, or on the column only (an unweighted adjacency: all ones; D^-1 (A+I), the
+// row-normalised adjacency of Kipf's pygcn; its transpose, which the backward pass multiplies with) ----
+__global__ void const_fill_kernel(float* __restrict__ p, int n, float v) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+__global__ void row_first_value_kernel(const int* __restrict__ rowptr, const float* __restrict__ val, int m, float* __restrict__ u_row) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < m) u_row[r] = rowptr[r] < rowptr[r + 1] ? val[rowptr[r]] : 0.f;
+}
+// u_col[c] = the value of SOME entry of column c (all of them are equal when the values are column-constant: the
+// racing stores then write the same bits; the check below decides)
+__global__ void col_any_value_kernel(const int* __restrict__ col, const float* __restrict__ val, int nnz, float* __restrict__ u_col) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < nnz; e += stride) u_col[col[e]] = val[e];
+}
+
+// mode 1: val[r, c] == u_row[r] (u_col = 1);  mode 2: val[r, c] == u_col[c] (u_row = 1).  u_row_out [m], u_col_out [n]
+// (device, caller-allocated); *ok_host = 1 when every stored entry matches within 4 ulp.
+hipError_t detect_constant_values(const int* rowptr, const int* col, const float* val, int m, int n, int nnz, int mode,
+                                  float* u_row_out, float* u_col_out, int* ok_host, hipStream_t st) {
+  *ok_host = 0;
+  if (m <= 0 || n <= 0 || nnz <= 0) return hipSuccess;
+  if (mode == 1) {
+    row_first_value_kernel<<<(m + 255) / 256, 256, 0, st>>>(rowptr, val, m, u_row_out);
+    const_fill_kernel<<<(n + 255) / 256, 256, 0, st>>>(u_col_out, n, 1.f);
+  } else {
+    const_fill_kernel<<<(m + 255) / 256, 256, 0, st>>>(u_row_out, m, 1.f);
+    const_fill_kernel<<<(n + 255) / 256, 256, 0, st>>>(u_col_out, n, 1.f);   // (columns without entries: any value)
+    col_any_value_kernel<<<4096, 256, 0, st>>>(col, val, nnz, u_col_out);
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  return verify_value_factors(rowptr, col, val, u_row_out, u_col_out, m, ok_host, st);
 }
 
 // caller-supplied factors: val[r, c] == u_row[r] * u_col[c] (4 ulp) for every stored entry of the m-row matrix?

@@ -160,5 +160,8 @@ hipError_t verify_value_factors(const int* rowptr, const int* col, const float* 
                                 const float* u_col, int m, int* ok_host, hipStream_t st);
 hipError_t detect_rank1_values(const int* rowptr, const int* col, const float* val, int n, float* u_out,
                                int* ok_host, hipStream_t st);
+// values that depend on the row only (mode 1: u_col = 1) or on the column only (mode 2: u_row = 1)?
+hipError_t detect_constant_values(const int* rowptr, const int* col, const float* val, int m, int n, int nnz, int mode,
+                                  float* u_row_out, float* u_col_out, int* ok_host, hipStream_t st);
 
 }  // namespace gcn

@@ -138,7 +138,12 @@ int gcn_spmm_plan_main_kernel(const gcn_spmm_plan_t* plan, int32_t k, int32_t ep
  * (GCN_ERR_INVALID_ARG otherwise); slices = 0/1 turns it off; slices = -1 picks the count from
  * (m, n, nnz) — off for low-degree graphs and tables that fit an L2 anyway, 2..8 otherwise — and silently stays off for
  * unsorted rows.  The matrix passed here must be the
- * one the plan was created for.  Costs one extra copy of col/val plus slices*m*k floats. */
+ * one the plan was created for.  Costs one extra copy of col/val plus slices*m*k floats.
+ * Values that factor as u_row[r]*u_col[c] — found here on the device, every entry checked to 4 ulp: the symmetric GCN
+ * normalisation D^-1/2 (A+I) D^-1/2 (square matrices), values that depend on the row only (an unweighted adjacency,
+ * the row-normalised D^-1 (A+I)) or on the column only (its transpose) — let the sliced pass run WITHOUT its value
+ * stream (B scaled by u_col in the copy it gathers from, rows scaled by u_row in the reduction; results within the
+ * 1e-5 contract).  gcn_spmm_plan_set_value_factors hands factors over for matrices that cannot see them (row blocks). */
 int gcn_spmm_plan_enable_slicing(gcn_spmm_plan_t* plan, const int32_t* rowptr_dev,
                                  const int32_t* col_dev, const float* val_dev,
                                  int32_t slices, void* stream);

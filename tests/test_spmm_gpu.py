@@ -538,6 +538,40 @@ def test_dropin_flexspmm_reads_its_launch_parameters_on_the_device():
     assert bool((C == 3.0).all())
 
 
+def test_row_constant_and_column_constant_values_take_the_value_free_pass_too():
+    """values that depend on the row only or on the column only factor as u_row[r]·1 / 1·u_col[c]: an unweighted
+    adjacency (all ones — sum aggregation), Kipf's row-normalised D^-1 (A+I) and its transpose (the backward pass of
+    that model) run the sliced pass without their value stream, found automatically; one entry off and they do not"""
+    n = 17000
+    rowptr, col, _ = sym_norm_graph(n, 1200000, seed=31)
+    nnz = len(col)
+    deg = np.diff(rowptr).astype(np.float32)
+    rows = np.repeat(np.arange(n), np.diff(rowptr))
+    rng = np.random.default_rng(6)
+    d = _dev()
+    B = rng.standard_normal((n, 64)).astype(np.float32)
+    Bd = torch.from_numpy(B).to(d)
+    cases = {"ones": np.ones(nnz, np.float32), "row-normalised": (1.0 / deg)[rows].astype(np.float32),
+             "column-normalised": (1.0 / deg)[col].astype(np.float32)}
+    for name, v in cases.items():
+        adj = _adj(rowptr, col, v, n, n)
+        assert adj.num_slices >= 2 and adj.has_value_factors, name
+        k_name = adj.main_kernel(64)
+        assert k_name.startswith("gcn::spmm_group") and "weighted" not in k_name, (name, k_name)
+        assert rel_err(adj.matmul_raw(Bd).cpu().numpy(), oracle_spmm(rowptr, col, v, B)) <= TOL, name
+        v2 = v.copy(); v2[nnz // 3] *= 1.001                                  # one entry off: the values travel again
+        adj2 = _adj(rowptr, col, v2, n, n)
+        assert not adj2.has_value_factors and "weighted" in adj2.main_kernel(64), name
+        assert rel_err(adj2.matmul_raw(Bd).cpu().numpy(), oracle_spmm(rowptr, col, v2, B)) <= TOL, name
+    # a rectangular block (rows 2000..12000) of the row-normalised matrix: detection does not need a square matrix
+    lo, hi = 2000, 12000
+    e0, e1 = int(rowptr[lo]), int(rowptr[hi])
+    v = cases["row-normalised"][e0:e1]
+    blk = _adj((rowptr[lo:hi + 1] - e0).astype(np.int32), col[e0:e1], v, hi - lo, n, slices=4)
+    assert blk.has_value_factors and "weighted" not in blk.main_kernel(64)
+    assert rel_err(blk.matmul_raw(Bd).cpu().numpy(), oracle_spmm((rowptr[lo:hi + 1] - e0).astype(np.int32), col[e0:e1], v, B)) <= TOL
+
+
 def test_prelaid_chain_needs_no_feature_copy_and_writes_the_next_layers_input():
     """gcn_spmm_csr_f32_prelaid: B handed over in the plan's slice-by-slice, column-scaled layout B' (no per-call copy),
     the result written straight into a consumer's B' (gapped rows, times the consumer's column factor).  A square
