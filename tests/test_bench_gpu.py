@@ -123,3 +123,20 @@ def test_config5_gorder_leg_loads_an_offline_rank_for_the_cpu_generated_graph(tm
         for f in (rank_f, meta_f):
             if os.path.exists(f):
                 os.remove(f)
+
+
+@pytest.mark.parametrize("exchange", ["all_gather", "direct"])
+def test_two_rank_rehearsal_with_the_prelaid_exchange_buffers(exchange):
+    """the N = 2 bench path on ONE GPU at a size where the pre-laid chain switches on (slots of whole column slices, the
+    exchange buffer is the next layer's scaled input): both ranks agree on the layout (one MIN all-reduce), exchange
+    their slots over gloo, and the all-reduced output check passes"""
+    env = dict(os.environ, GCN_AMD_BENCH_REHEARSAL="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29741", os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--scale", "0.12", "--steps", "3", "--warmup", "1", "--exchange", exchange],
+                         cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["check"]["passed"] and d["check"]["rel_err"] <= 1e-5
+    assert d["config"]["prelaid"] is True and d["roofline"]["slices"] >= 2
+    assert "scaling_budget" in d and d["roofline"]["concurrent_planes"] == 2
