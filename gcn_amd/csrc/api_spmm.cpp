@@ -73,6 +73,7 @@ int group_store() {                                                             
 }
 bool group_ring() { static const bool v = env_on("GCN_AMD_GROUP_RING"); return v; }   // finished rows through the LDS ring (value-free pass)
 bool group_merge_tiles() { static const bool v = env_on("GCN_AMD_GROUP_MERGE_TILES"); return v; }   // all column tiles in one launch
+bool group_fused_fixup() { static const bool v = env_on("GCN_AMD_GROUP_FUSED_FIXUP"); return v; }   // cut rows' pieces added by the slice reduction (no fix-up pass)
 bool group8_enabled() { static const bool v = env_on("GCN_AMD_GROUP8"); return v; }   // k <= 32: eight 8-lane row engines per wave
 bool group_weighted_enabled() { static const bool v = env_on("GCN_AMD_GROUP_WEIGHTED"); return v; }   // group kernel for values that do not factor
 bool quad_stream_rows() { static const bool v = env_on("GCN_AMD_QUAD_NT"); return v; }   // sliced pass with values: nt partial-row stores
@@ -440,9 +441,13 @@ int spmm_impl(gcn_spmm_plan* p, const int32_t* rowptr, const int32_t* col, const
     if (ev0 && hipEventRecord(ev0, st) != hipSuccess) return GCN_ERR_HIP;
     if (gcn::launch_spmm_group(ga, st) != hipSuccess) return GCN_ERR_HIP;
     if (ev1 && hipEventRecord(ev1, st) != hipSuccess) return GCN_ERR_HIP;
-    if (gcn::launch_group_fixup(p->group.fix, p->group.nfix, p->ws, p->cv, k, st) != hipSuccess) return GCN_ERR_HIP;
+    // rows cut by chunk ends: their later pieces are added by the reduction itself (cut lists per output row), or —
+    // GCN_AMD_GROUP_FUSED_FIXUP=0, or a plan without the lists — by a pass of their own in front of it
+    gcn::CutLists cuts;
+    if (gcn::group_fused_fixup() && p->group.cutptr) { cuts.ptr = p->group.cutptr; cuts.chunk = p->group.cutchunk; cuts.P = p->ws; }
+    else if (gcn::launch_group_fixup(p->group.fix, p->group.nfix, p->ws, p->cv, k, st) != hipSuccess) return GCN_ERR_HIP;
     return gcn::launch_slice_reduce(p->cv, C, bias, relu, p->m, sl.S, k, st, 0, weighted ? nullptr : p->factors.u_row.get(),
-                                    epi.drop, nullptr, epi.outscale, epi.gap_w) == hipSuccess ? GCN_OK : GCN_ERR_HIP;
+                                    epi.drop, nullptr, epi.outscale, epi.gap_w, cuts) == hipSuccess ? GCN_OK : GCN_ERR_HIP;
   }
   a.rowptr = sl.vrowptr; a.col = sl.vcol; a.val = sl.vval; a.chunk_row = sl.vchunk_row;
   a.C = p->cv; a.m = sl.S * p->m; a.bias = nullptr; a.relu = 0;
@@ -476,11 +481,13 @@ void build_sliced_streams(gcn_spmm_plan* p, hipStream_t st) {
     unsigned short* stream = nullptr;
     float* vals = nullptr;
     int *chunk_row = nullptr, *chunk_meta = nullptr, *fix = nullptr, nch = 0, nfix = 0;
+    int *cutptr = nullptr, *cutchunk = nullptr, ncut = 0;
     const int gT = gcn::group_chunk(p->nnz, p->cu_count);
     if (gcn::build_group_stream(sl.vrowptr, sl.vcol, p->m, p->n, sl.S, gT, p->group.vrowptr, &stream,
                                 &chunk_row, &chunk_meta, &nch, &fix, &nfix, st, value_free ? nullptr : sl.vval.get(),
-                                value_free ? nullptr : &vals) == hipSuccess && nch > 0) {
+                                value_free ? nullptr : &vals, &cutptr, &cutchunk, &ncut) == hipSuccess && nch > 0) {
       p->group.fix.adopt(fix, 4 * (size_t)nfix); p->group.nfix = nfix;
+      p->group.cutptr.adopt(cutptr, (size_t)p->m + 1); p->group.cutchunk.adopt(cutchunk, (size_t)(ncut > 0 ? ncut : 1)); p->group.ncut = ncut;
       p->group.stream.adopt(stream, (size_t)nch * (size_t)gT);
       if (vals) p->group.vals.adopt(vals, (size_t)nch * (size_t)gT);
       p->group.chunk_row.adopt(chunk_row, (size_t)nch);

@@ -108,7 +108,8 @@ struct GroupStream {
   DevBuf<float> vals;                               // [nchunks*T] values in stream order (weighted pass), empty: value-free
   DevBuf<int> chunk_row, vrowptr, chunk_meta;       // [nchunks], [S*m+1], int2 [nchunks]
   DevBuf<int> fix;                                  // int4 [nfix]: rows cut by chunk ends {virtual row, c, c1, 0}
-  int nchunks = 0, T = 0, w = 0, nfix = 0;
+  DevBuf<int> cutptr, cutchunk;                     // the same pieces per OUTPUT row (CutLists): [m+1], [ncut] chunk numbers
+  int nchunks = 0, T = 0, w = 0, nfix = 0, ncut = 0;
   bool ready() const { return stream != nullptr; }
 };
 

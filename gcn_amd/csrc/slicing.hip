@@ -21,6 +21,8 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 #include <stdint.h>
+#include <stdlib.h>
+#include <type_traits>
 #include <vector>
 #include "spmm_kernels.h"
 
@@ -91,12 +93,13 @@ __global__ void __launch_bounds__(256)
 slice_reduce_kernel(const float* __restrict__ Cv, float* __restrict__ C,
                     const float* __restrict__ bias, int relu, int m, int S, int k, int accumulate,
                     const float* __restrict__ rowscale, DropoutSpec drop, const int* __restrict__ guard,
-                    const float* __restrict__ outscale, int gap_w) {
+                    const float* __restrict__ outscale, int gap_w, CutLists cuts) {
   if (guard && *guard == 0) return;
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int nw = gridDim.x * 4;
   for (int r = wave; r < m; r += nw) {
+    const int q0 = cuts.ptr ? cuts.ptr[r] : 0, q1 = cuts.ptr ? cuts.ptr[r + 1] : 0;   // head pieces of this row's cut slices
     const float rs = (rowscale ? rowscale[r] : 1.f);
     const float os = outscale ? outscale[r] : 1.f;             // the consumer's column factor (pre-laid output, see below)
     const size_t orow = gap_w > 0 ? (size_t)r + (size_t)(r / gap_w) : (size_t)r;    // value-free main pass: the row's own factor u[r]
@@ -113,6 +116,11 @@ slice_reduce_kernel(const float* __restrict__ Cv, float* __restrict__ C,
 #pragma unroll
           for (int i = 0; i < VEC; ++i) acc[i] += p[i];
         }
+      }
+      for (int q = q0; q < q1; ++q) {               // (row, chunk) order: slice by slice, as the pieces lie in the stream
+        const float* p = cuts.P + (size_t)(2 * cuts.chunk[q]) * (size_t)k + x;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i] += p[i];
       }
       if (rowscale) {
 #pragma unroll
@@ -158,33 +166,62 @@ slice_reduce_kernel(const float* __restrict__ Cv, float* __restrict__ C,
 // eight at a time with non-temporal loads (they are read exactly once) before they are added in slice order.
 typedef float slice_f32x4 __attribute__((ext_vector_type(4)));
 
+// OFF32: a plane of partial rows is smaller than 4 GiB, so a lane's place in it is a 32-bit byte offset beside a
+// wave-uniform plane pointer (one address register per lane instead of a 64-bit pointer per load in flight): the
+// kernel lives on loads in flight, and with the cut-row pieces it dropped from five to four waves per SIMD without this.
+template <bool DROP, bool OFF32>
 __global__ void __launch_bounds__(256)
 slice_reduce_wide_kernel(const float* __restrict__ Cv, float* __restrict__ C,
                          const float* __restrict__ bias, int relu, int m, int S, int k, int accumulate,
                          const float* __restrict__ rowscale, DropoutSpec drop, const int* __restrict__ guard,
-                         const float* __restrict__ outscale, int gap_w) {
+                         const float* __restrict__ outscale, int gap_w, CutLists cuts) {
   if (guard && *guard == 0) return;
+  typedef typename std::conditional<OFF32, unsigned, size_t>::type off_t;
   const int lane = threadIdx.x & 63;
   const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const long long nw = (long long)gridDim.x * 4;
   const int rpw = 256 / k;                            // rows per wave and step
   const int lr = lane * 4 / k, x = lane * 4 % k;
   const size_t slab = (size_t)m * (size_t)k;          // floats between two slices' partial rows of one row
+  const char* const Cvb = reinterpret_cast<const char*>(Cv);
+  const char* const Pb = reinterpret_cast<const char*>(cuts.P);
+  const off_t xb = (off_t)x * 4;
+  // rows cut by chunk ends of the group kernels' stream: Cv holds the first piece, the following chunks' head pieces lie in
+  // the slab P — about one per output row at 15 slices.  Two dependent index loads stand in front of a piece: they are
+  // issued one row step AHEAD (nq0 / nq1 / nc0), so that a step only waits for its slices
+  int nq0 = 0, nq1 = 0, nc0 = 0;
+  if (cuts.ptr && wave * rpw + lr < m) {
+    nq0 = cuts.ptr[wave * rpw + lr]; nq1 = cuts.ptr[wave * rpw + lr + 1];
+    nc0 = nq0 < nq1 ? cuts.chunk[nq0] : 0;
+  }
   for (long long r0 = wave * rpw; r0 < m; r0 += nw * rpw) {
     const long long r = r0 + lr;
     if (r >= m) continue;
-    const float* p = Cv + (size_t)r * (size_t)k + x;
+    const off_t off = ((off_t)r * (off_t)k + (off_t)x) * 4;      // bytes inside a plane
+    const int q0 = nq0, q1 = nq1;
+    slice_f32x4 pv = {0.f, 0.f, 0.f, 0.f};             // the first piece: on its way while the slices are added
+    if (q0 < q1) pv = __builtin_nontemporal_load(reinterpret_cast<const slice_f32x4*>(Pb + (size_t)(2 * nc0) * (size_t)k * 4 + xb));
+    const long long rn = r + nw * rpw;
+    if (cuts.ptr && rn < m) {
+      nq0 = cuts.ptr[rn]; nq1 = cuts.ptr[rn + 1];
+      nc0 = nq0 < nq1 ? cuts.chunk[nq0] : 0;
+    }
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     int s = 0;
     for (; s + 8 <= S; s += 8) {
       slice_f32x4 v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(reinterpret_cast<const slice_f32x4*>(p + (size_t)(s + u) * slab));
+      for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(reinterpret_cast<const slice_f32x4*>(Cvb + (size_t)(s + u) * slab * 4 + off));
 #pragma unroll
       for (int u = 0; u < 8; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
     }
     for (; s < S; ++s) {
-      const slice_f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const slice_f32x4*>(p + (size_t)s * slab));
+      const slice_f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const slice_f32x4*>(Cvb + (size_t)s * slab * 4 + off));
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    if (q0 < q1) { acc.x += pv.x; acc.y += pv.y; acc.z += pv.z; acc.w += pv.w; }
+    for (int q = q0 + 1; q < q1; ++q) {               // (row, chunk) order: slice by slice, as the pieces lie in the stream
+      const slice_f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const slice_f32x4*>(Pb + (size_t)(2 * cuts.chunk[q]) * (size_t)k * 4 + xb));
       acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
     if (rowscale) { const float rs = rowscale[r]; acc.x *= rs; acc.y *= rs; acc.z *= rs; acc.w *= rs; }
@@ -201,7 +238,7 @@ slice_reduce_wide_kernel(const float* __restrict__ Cv, float* __restrict__ C,
       acc.x += b.x; acc.y += b.y; acc.z += b.z; acc.w += b.w;
     }
     if (relu) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
-    if (drop.on())                                    // the dropout mask of the fused epilogue (philox.h)
+    if constexpr (DROP)                               // the dropout mask of the fused epilogue (philox.h)
       acc = dropout_apply4(drop, (unsigned long long)r * (unsigned long long)k + (unsigned long long)x, acc);
     if (outscale) { const float os = outscale[r]; acc.x *= os; acc.y *= os; acc.z *= os; acc.w *= os; }
     *reinterpret_cast<float4*>(o) = acc;
@@ -264,17 +301,24 @@ hipError_t build_sliced_csr(const int* rowptr, const int* col, const float* val,
 
 hipError_t launch_slice_reduce(const float* Cv, float* C, const float* bias, int relu, int m, int S,
                                int k, hipStream_t st, int accumulate, const float* rowscale, const DropoutSpec& drop,
-                               const int* guard, const float* outscale, int gap_w) {
+                               const int* guard, const float* outscale, int gap_w, const CutLists& cuts) {
   if (m <= 0 || k <= 0) return hipSuccess;
   int nb = (m + 3) / 4;
   if (nb > 8192) nb = 8192;
-  const uintptr_t al = (uintptr_t)Cv | (uintptr_t)C | (uintptr_t)bias;
+  const uintptr_t al = (uintptr_t)Cv | (uintptr_t)C | (uintptr_t)bias | (uintptr_t)cuts.P;
   if (k % 4 == 0 && 256 % k == 0 && (al & 15) == 0) {
     const long long steps = ((long long)m * k + 255) / 256;      // wave steps of 1 KiB
-    const int nbw = (int)(steps / 4 + 1 < 16384 ? steps / 4 + 1 : 16384);
-    slice_reduce_wide_kernel<<<nbw, 256, 0, st>>>(Cv, C, bias, relu, m, S, k, accumulate, rowscale, drop, guard, outscale, gap_w);
-  } else if (k % 4 == 0 && (al & 15) == 0) slice_reduce_kernel<4><<<nb, 256, 0, st>>>(Cv, C, bias, relu, m, S, k, accumulate, rowscale, drop, guard, outscale, gap_w);
-  else                              slice_reduce_kernel<1><<<nb, 256, 0, st>>>(Cv, C, bias, relu, m, S, k, accumulate, rowscale, drop, guard, outscale, gap_w);
+    static const int cap_env = [] { const char* e = getenv("GCN_AMD_REDUCE_BLOCKS"); return e ? atoi(e) : 0; }();   // development knob
+    const int cap = cap_env > 0 ? cap_env : 16384;
+    const int nbw = (int)(steps / 4 + 1 < cap ? steps / 4 + 1 : cap);
+    const bool off32 = (size_t)m * (size_t)k * 4 < (1ull << 32);   // a lane's byte offset inside a plane of partial rows
+    static const int lds_env = [] { const char* e = getenv("GCN_AMD_REDUCE_LDS"); return e ? atoi(e) : 0; }();   // development: LDS bytes per block = an occupancy limit
+#define GCN_RW(D, O) slice_reduce_wide_kernel<D, O><<<nbw, 256, (size_t)lds_env, st>>>(Cv, C, bias, relu, m, S, k, accumulate, rowscale, drop, guard, outscale, gap_w, cuts)
+    if (drop.on()) { if (off32) GCN_RW(true, true); else GCN_RW(true, false); }
+    else           { if (off32) GCN_RW(false, true); else GCN_RW(false, false); }
+#undef GCN_RW
+  } else if (k % 4 == 0 && (al & 15) == 0) slice_reduce_kernel<4><<<nb, 256, 0, st>>>(Cv, C, bias, relu, m, S, k, accumulate, rowscale, drop, guard, outscale, gap_w, cuts);
+  else                              slice_reduce_kernel<1><<<nb, 256, 0, st>>>(Cv, C, bias, relu, m, S, k, accumulate, rowscale, drop, guard, outscale, gap_w, cuts);
   return hipGetLastError();
 }
 
@@ -420,8 +464,30 @@ __global__ void group_fix_list_kernel(const int2* __restrict__ meta, const int* 
   fix[atomicAdd(nfix, 1)] = make_int4(vr, c, (vrowptr_g[vr + 1] - 1) / T, 0);
 }
 
-// Cv[row, :] = tail piece of chunk c-1 + head pieces of chunks c .. c1, in chunk order.  One thread per float4
-// of FOUR list entries (the loads of the four are in flight together: the pass is latency-bound otherwise).
+// Cut lists for the slice reduction: every chunk c that continues a row begun earlier holds one head piece P[2c] of
+// output row r = (virtual row) % m.  keys[c] = (r << 32) | c, all ones for the other chunks (they sort to the end);
+// cnt[r] = pieces of row r.  Sorted keys = the pieces in (row, chunk) order — chunks ascend with the slice, so a row's
+// pieces follow each other as its slices do.
+__global__ void group_cut_keys_kernel(const int2* __restrict__ meta, int nchunks, int m, unsigned long long* __restrict__ keys,
+                                      int* __restrict__ cnt) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nchunks) return;
+  const int2 mt = meta[c];
+  if (c == 0 || !(mt.x & 1)) { keys[c] = ~0ull; return; }
+  const int r = (mt.x >> 1) % m;
+  keys[c] = ((unsigned long long)(unsigned)r << 32) | (unsigned)c;
+  atomicAdd(cnt + r, 1);
+}
+
+__global__ void group_cut_chunks_kernel(const unsigned long long* __restrict__ keys, int ncut, int* __restrict__ chunk) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < ncut) chunk[i] = (int)(unsigned)keys[i];
+}
+
+// Cv[row, :] += head pieces of chunks c .. c1, in chunk order (Cv[row] holds the row's first piece: the group kernels
+// write the piece that sticks out of chunk c-1 there).  One thread per float4 of FOUR list entries (the loads of the
+// four are in flight together: the pass is latency-bound otherwise).  The plans of api_spmm.cpp do not run this pass:
+// their slice reduction adds the same pieces in the same order (CutLists); the drop-in flexspmm does.
 __global__ void __launch_bounds__(256)
 group_fixup_kernel(const int4* __restrict__ fix, int nfix, const float* __restrict__ P, float* __restrict__ Cv, int k,
                    const int* __restrict__ dyn) {
@@ -437,7 +503,7 @@ group_fixup_kernel(const int4* __restrict__ fix, int nfix, const float* __restri
   for (int i = 0; i < 4; ++i) f[i] = fix[e0 + i < nfix ? e0 + i : e0];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    a[i] = *reinterpret_cast<const float4*>(P + (size_t)(2 * (f[i].y - 1) + 1) * (size_t)k + x);
+    a[i] = *reinterpret_cast<const float4*>(Cv + (size_t)f[i].x * (size_t)k + x);
     b[i] = *reinterpret_cast<const float4*>(P + (size_t)(2 * f[i].y) * (size_t)k + x);
   }
 #pragma unroll
@@ -463,8 +529,11 @@ hipError_t launch_group_fixup(const int* fix, int nfix, const float* P, float* C
 hipError_t build_group_stream(const int* vrowptr, const int* vcol, int m, int n, int S, int T, int* vrowptr_g,
                               unsigned short** stream_out, int** chunk_row_out, int** chunk_meta_out,
                               int* nchunks_host, int** fix_out, int* nfix_host, hipStream_t st,
-                              const float* vval, float** vals_out) {
+                              const float* vval, float** vals_out, int** cutptr_out, int** cutchunk_out, int* ncut_host) {
   if (vals_out) *vals_out = nullptr;
+  if (cutptr_out) *cutptr_out = nullptr;
+  if (cutchunk_out) *cutchunk_out = nullptr;
+  if (ncut_host) *ncut_host = 0;
   *stream_out = nullptr; *chunk_row_out = nullptr; *chunk_meta_out = nullptr; *nchunks_host = 0;
   *fix_out = nullptr; *nfix_host = 0;
   const int w = (n + S - 1) / S;
@@ -475,10 +544,21 @@ hipError_t build_group_stream(const int* vrowptr, const int* vcol, int m, int n,
   int4* fix = nullptr;
   float* vals = nullptr;
   unsigned short* stream = nullptr;
+  int *cutptr = nullptr, *cutchunk = nullptr, *cutcnt = nullptr;
+  unsigned long long *ckeys = nullptr, *ckeys2 = nullptr;
+  void* ctmp = nullptr;
   void* tmp = nullptr;
   size_t tmp_bytes = 0;
   hipError_t err = hipSuccess;
   auto cleanup = [&](bool all) {
+    if (cutcnt) (void)hipFree(cutcnt);
+    if (ckeys) (void)hipFree(ckeys);
+    if (ckeys2) (void)hipFree(ckeys2);
+    if (ctmp) (void)hipFree(ctmp);
+    if (all) {
+      if (cutptr) (void)hipFree(cutptr);
+      if (cutchunk) (void)hipFree(cutchunk);
+    }
     if (len) (void)hipFree(len);
     if (pos) (void)hipFree(pos);
     if (d_pad) (void)hipFree(d_pad);
@@ -543,7 +623,33 @@ hipError_t build_group_stream(const int* vrowptr, const int* vcol, int m, int n,
   GCN_GO(hipGetLastError());
   int nfix = 0;
   GCN_GO(hipMemcpyAsync(&nfix, nfix_dev, sizeof(int), hipMemcpyDeviceToHost, st));
-  GCN_GO(hipStreamSynchronize(st));                              // (pad_before and nfix are host buffers)
+  int ncut = 0;
+  if (cutptr_out && cutchunk_out && ncut_host) {                 // the same pieces per OUTPUT row, for the slice reduction
+    GCN_GO(hipMalloc((void**)&cutcnt, sizeof(int) * (size_t)(m + 1)));
+    GCN_GO(hipMalloc((void**)&cutptr, sizeof(int) * (size_t)(m + 1)));
+    GCN_GO(hipMalloc((void**)&ckeys, sizeof(unsigned long long) * (size_t)nchunks));
+    GCN_GO(hipMalloc((void**)&ckeys2, sizeof(unsigned long long) * (size_t)nchunks));
+    GCN_GO(hipMemsetAsync(cutcnt, 0, sizeof(int) * (size_t)(m + 1), st));
+    group_cut_keys_kernel<<<(nchunks + 255) / 256, 256, 0, st>>>(meta, nchunks, m, ckeys, cutcnt);
+    GCN_GO(hipGetLastError());
+    size_t b1 = 0, b2 = 0;
+    GCN_GO(hipcub::DeviceScan::ExclusiveSum(nullptr, b1, cutcnt, cutptr, m + 1, st));
+    GCN_GO(hipcub::DeviceRadixSort::SortKeys(nullptr, b2, ckeys, ckeys2, nchunks, 0, 64, st));
+    GCN_GO(hipMalloc(&ctmp, (b1 > b2 ? b1 : b2) + 16));
+    GCN_GO(hipcub::DeviceScan::ExclusiveSum(ctmp, b1, cutcnt, cutptr, m + 1, st));
+    GCN_GO(hipcub::DeviceRadixSort::SortKeys(ctmp, b2, ckeys, ckeys2, nchunks, 0, 64, st));
+    GCN_GO(hipMemcpyAsync(&ncut, cutptr + m, sizeof(int), hipMemcpyDeviceToHost, st));
+  }
+  GCN_GO(hipStreamSynchronize(st));                              // (pad_before, nfix and ncut are host buffers)
+  if (cutptr) {
+    GCN_GO(hipMalloc((void**)&cutchunk, sizeof(int) * (size_t)(ncut > 0 ? ncut : 1)));
+    if (ncut > 0) {
+      group_cut_chunks_kernel<<<(ncut + 255) / 256, 256, 0, st>>>(ckeys2, ncut, cutchunk);
+      GCN_GO(hipGetLastError());
+      GCN_GO(hipStreamSynchronize(st));
+    }
+    *cutptr_out = cutptr; *cutchunk_out = cutchunk; *ncut_host = ncut;
+  }
 #undef GCN_GO
   cleanup(false);
   *stream_out = stream; *chunk_row_out = chunk_row; *chunk_meta_out = reinterpret_cast<int*>(meta); *nchunks_host = nchunks;

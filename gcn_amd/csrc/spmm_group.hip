@@ -25,8 +25,9 @@
 // of an XCD take consecutive chunks in dispatch order, so an XCD walks its part of the stream front to
 // back and slices meet its L2 one after the other (with more chunks per wave, as before, the second
 // chunk of an early wave ran beside the first chunk of a late one: two slices in one L2).
-// Row pieces that cross chunk ends go to the partial slab P and are added by group_fixup_kernel (slicing.hip) in chunk
-// order, as everywhere else: results are bitwise reproducible.
+// A row cut by chunk ends leaves its first piece in Cv[row] and the pieces of the following chunks in the slab P (one
+// head piece per chunk); the slice reduction adds them behind the row's slices, in chunk order (cut lists, slicing.hip;
+// group_fixup_kernel does the same as a pass of its own where the reduction cannot): results are bitwise reproducible.
 //
 // Value-free (spmm_group_kernel: every stored entry counts 1; the caller gathers from a copy of B whose rows
 // were scaled by u_col and scales finished rows by u_row, api_spmm.cpp) or, for values that do not factor,
@@ -215,10 +216,12 @@ group_walk(const unsigned short* __restrict__ stream, const float* __restrict__ 
     if (some & 0x0001000000000000ull) GCN_G_DRAIN(3, __builtin_amdgcn_readlane(ring_n, 48))
   }
 #undef GCN_G_DRAIN
-  // the row piece that sticks out of the chunk's end (the last entry did not end its row)
+  // the row piece that sticks out of the chunk's end (the last entry did not end its row): it is the FIRST piece of its
+  // row — unless the whole chunk lies inside one row, then it is this chunk's head piece — and goes where the row's
+  // partial sum lives, Cv[row]; the pieces of the chunks the row runs on into (their head pieces, P[2c]) are added by
+  // the slice reduction (cut lists) or by group_fixup_kernel
   if (!row_bcast<15>((int)fl)) {
-    float* dst = (head && first) ? ptr : P + (size_t)(2 * c + 1) * kk + fcol;
-    if (fok) store_row_piece<POLICY>(dst, acc);
+    if (fok) store_row_piece<POLICY>(ptr, acc);
   }
 }
 
@@ -436,8 +439,7 @@ group8_walk(const unsigned short* __restrict__ stream, const float* __restrict__
 #undef GCN_G8_DRAIN
   // the row piece that sticks out of the chunk's end (the chunk's last entry — entry 7 of its last block — did not end its row)
   if (!row_ror8_bcast<7>((int)fl1, __builtin_amdgcn_mov_dpp((int)fl1, 0x128, 0xf, 0xf, true), upper)) {
-    float* dst = (head && first) ? ptr : P + (size_t)(2 * c + 1) * kk + fcol;
-    if (fok) store_row_piece<2>(dst, acc);
+    if (fok) store_row_piece<2>(ptr, acc);                        // (to Cv[row], or the chunk's head piece: as in group_walk)
   }
 }
 

@@ -99,8 +99,11 @@ bool spmm_group8_applies(const GroupArgs& a);
 hipError_t build_group_stream(const int* vrowptr, const int* vcol, int m, int n, int S, int T, int* vrowptr_g,
                               unsigned short** stream_out, int** chunk_row_out, int** chunk_meta_out,
                               int* nchunks_host, int** fix_out, int* nfix_host, hipStream_t st,
-                              const float* vval = nullptr, float** vals_out = nullptr);
-// Cv[row, :] = sum of the row's pieces in the partial slab P, in chunk order, for every row of the list (k % 4 == 0)
+                              const float* vval = nullptr, float** vals_out = nullptr,
+                              int** cutptr_out = nullptr, int** cutchunk_out = nullptr, int* ncut_host = nullptr);
+// cutptr_out / cutchunk_out / ncut_host (optional; allocated here): the same cut rows keyed by OUTPUT row, for the slice
+// reduction — pieces cutchunk[cutptr[r] .. cutptr[r+1]) (chunk numbers; the piece of chunk c is P[2c]) belong to row r.
+// Cv[row, :] += the row's head pieces in the partial slab P, in chunk order, for every row of the list (k % 4 == 0)
 // dyn (drop-in flexspmm): nfix is an upper bound, the count is dyn[2] and nothing runs when dyn[0] == 0
 hipError_t launch_group_fixup(const int* fix, int nfix, const float* P, float* Cv, int k, hipStream_t s,
                               const int* dyn = nullptr);
@@ -149,10 +152,18 @@ hipError_t build_col16_stream(const int* vrowptr, const int* vcol, int m, int n,
 hipError_t build_sliced_csr(const int* rowptr, const int* col, const float* val, int m, int n,
                             int nnz, int S, int* vrowptr, int* vcol, float* vval,
                             int* sorted_out, hipStream_t st);
+// rows of the group kernels' stream cut by chunk ends, per output row (build_group_stream): the reduction adds the pieces
+// P[2 * chunk[q]], q in [ptr[r], ptr[r+1]), behind the S partial rows of row r — the fix-up pass folded into the reduction
+struct CutLists {
+  const int* ptr = nullptr;      // [m+1]; null: no pieces to add
+  const int* chunk = nullptr;    // [ptr[m]]
+  const float* P = nullptr;      // the piece slab of the launch (GroupArgs::P)
+};
 hipError_t launch_slice_reduce(const float* Cv, float* C, const float* bias, int relu, int m, int S,
                                int k, hipStream_t st, int accumulate = 0, const float* rowscale = nullptr,
                                const DropoutSpec& drop = DropoutSpec{}, const int* guard = nullptr,   // guard: skip when *guard == 0
-                               const float* outscale = nullptr, int gap_w = 0);   // pre-laid output: row r -> r + r / gap_w, times outscale[r]
+                               const float* outscale = nullptr, int gap_w = 0,    // pre-laid output: row r -> r + r / gap_w, times outscale[r]
+                               const CutLists& cuts = CutLists{});
 // dst[i] = dropout(src[i]) for i < total, mask from the flat index i (dst may be src)
 hipError_t launch_dropout(float* dst, const float* src, long long total, const DropoutSpec& drop, hipStream_t st);
 // values factor as u[r]*u[c]?  u_out[n] (device), *ok_host = 1 when every stored entry matches within 4 ulp

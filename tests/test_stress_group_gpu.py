@@ -135,7 +135,40 @@ def test_group_kernels_with_64_bit_slice_bases():
     assert out.returncode == 0 and "big ok" in out.stdout, out.stdout[-1500:] + out.stderr[-1500:]
 
 
+def _fixup_child():
+    """runs in a child process with GCN_AMD_GROUP_FUSED_FIXUP=0: the cut rows' pieces added by group_fixup_kernel in a
+    pass of its own (what the drop-in flexspmm runs) instead of inside the slice reduction — against the fp64 oracle"""
+    d = torch.device("cuda:0")
+    for seed in range(12):
+        n, rowptr, col, val, rng = _graph(seed + 40)
+        S = int(rng.choice([2, 3, 5, 8, 13, 16]))
+        if seed % 3 == 2:
+            val = (val * (1.0 + 0.5 * rng.random(len(val)))).astype(np.float32)
+        adj = gcn_amd.CsrAdjacency(torch.from_numpy(rowptr).to(d), torch.from_numpy(col).to(d), torch.from_numpy(val).to(d),
+                                   (n, n), slices=S)
+        for k in (int(rng.choice([36, 64, 100, 128, 41, 192])), int(rng.choice([12, 16, 20, 24, 32]))):
+            B = rng.standard_normal((n, k)).astype(np.float32)
+            C = adj.matmul_raw(torch.from_numpy(B).to(d))
+            err = rel_err(C.cpu().numpy(), oracle_spmm(rowptr, col, val, B))
+            assert err <= TOL, (seed, n, S, k, adj.main_kernel(k), err)
+    print("fixup ok")
+
+
+def test_group_kernels_with_the_fix_up_pass_of_its_own():
+    """GCN_AMD_GROUP_FUSED_FIXUP=0: the same plans with group_fixup_kernel in front of the slice reduction (the default adds
+    the pieces inside the reduction), in ONE child process"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GCN_AMD_GROUP_FUSED_FIXUP="0", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    out = subprocess.run([sys.executable, os.path.abspath(__file__), "--fixup-child"], env=env, capture_output=True, text=True,
+                         timeout=600, cwd=os.path.dirname(os.path.abspath(__file__)))
+    assert out.returncode == 0 and "fixup ok" in out.stdout, out.stdout[-1500:] + out.stderr[-1500:]
+
+
 if __name__ == "__main__":
     import sys
     if "--big-child" in sys.argv:
         _big_child()
+    if "--fixup-child" in sys.argv:
+        _fixup_child()
