@@ -38,6 +38,7 @@ def test_default_invocation_prints_the_contract_line_with_roofline_and_cpu_basel
     assert chk["passed"] and 0 <= chk["rel_err"] <= 1e-5 and chk["rows_per_rank"] > 0
     c = d["cpu_baseline"]
     assert c["kind"] == "reference" and c["value"] > 0 and c["cores"] >= 1 and "torch.spmm" in c["sample"]
+    assert 0 < d["config"]["plan_build_seconds"] < 60           # device CSR -> plan + first SpMM, outside the timed steps
 
 
 @pytest.mark.parametrize("flags", [("--no-cpu-baseline", "--force-shard"), ("--no-cpu-baseline", "--sim-world", "4"),
