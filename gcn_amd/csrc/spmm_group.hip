@@ -57,8 +57,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // only sc1 and nt keep the written lines from displacing the table.  (There is no builtin for a 16-byte sc1
 // store; the trailing s_nop keeps the compiler's next instruction off the data registers until the store has
 // read them, cdna_hip_programming.md §5.7.)
+// GCN_ABLATE (development builds only, tools/ablate_group.sh: wrong results, exact costs): bit 0 no partial-row stores,
+// bit 1 no row-end handling, bit 2 no stream loads after the first run, bit 3 partial rows at a stride of 64 floats
+#ifndef GCN_ABLATE
+#define GCN_ABLATE 0
+#endif
 template <int POLICY>
 __device__ __forceinline__ void store_row_piece(float* dst, const float4& v) {
+  if constexpr ((GCN_ABLATE & 1) != 0) { asm volatile("" : : "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w)); return; }
   const f32x4 t = {v.x, v.y, v.z, v.w};
   if constexpr (POLICY == 1) {
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(dst), "v"(t) : "memory");
@@ -110,7 +116,7 @@ group_walk(const unsigned short* __restrict__ stream, const float* __restrict__ 
   const unsigned row_bytes = (unsigned)ldb * 4u;
   const unsigned foff = (unsigned)(fok ? fcol : col_tile * 64) * 4u;
   const char* Bb = reinterpret_cast<const char*>(Bp);
-  const size_t kk = (size_t)k;
+  const size_t kk = (GCN_ABLATE & 8) ? (size_t)64 : (size_t)k;  // (bit 3: partial rows of a tile contiguous — a layout experiment)
 
   const int2 meta = chunk_meta[c];                              // one load: nothing else stands before the first gather
   const int vrow = meta.x >> 1;                                 // virtual row holding the chunk's first entry
@@ -153,7 +159,7 @@ group_walk(const unsigned short* __restrict__ stream, const float* __restrict__ 
 #pragma unroll 1
   for (int blk = 0; blk < T / 16; ++blk) {
     const int j = blk & 3;
-    if (j == 0 && blk + 4 < T / 16) {                           // the next run, a whole run ahead of its use
+    if (j == 0 && blk + 4 < T / 16 && !(GCN_ABLATE & 4)) {      // the next run, a whole run ahead of its use
       const int nx = (blk / 4 + 1) * 16;
       eq_nx = stream_nt ? __builtin_nontemporal_load(sp + nx) : sp[nx];
       if constexpr (VALS) vq_nx = stream_nt ? __builtin_nontemporal_load(vp + nx) : vp[nx];
@@ -170,7 +176,7 @@ group_walk(const unsigned short* __restrict__ stream, const float* __restrict__ 
     b[UU] = *reinterpret_cast<const float4*>(Bb + (size_t)((unsigned)row_bcast<UU>(rowoff) + foff));
     GCN_G_ALL(GCN_G_GATHER)
 #undef GCN_G_GATHER
-    const unsigned long long ends = __ballot(fl != 0);          // bit g*16+u: entry u of group g ends a row
+    const unsigned long long ends = (GCN_ABLATE & 2) ? 0ull : __ballot(fl != 0);   // bit g*16+u: entry u of group g ends a row
     if (ends == 0ull) {
 #define GCN_G_ADD(UU)                                                                               \
       if constexpr (VALS) {                                                                         \
@@ -509,13 +515,15 @@ hipError_t launch_group_tp(const GroupArgs& a, int ldb, hipStream_t s) {
   const int blocks_per_tile = nblocks;
   nblocks *= tiles_per_launch;
   const int2* meta = reinterpret_cast<const int2*>(a.chunk_meta);
+  // development: dynamic LDS bytes per block = an occupancy limit (160 KiB per CU; the ring kernel holds 16 KiB itself)
+  static const size_t lds_env = [] { const char* e = getenv("GCN_AMD_GROUP_LDS"); return e ? (size_t)atoi(e) : (size_t)0; }();
   for (int t = 0; t < tiles; t += tiles_per_launch) {
     if (a.vals)
-      spmm_group_weighted_kernel<POLICY, BIG><<<dim3(nblocks), dim3(256), 0, s>>>(a.stream, a.vals, meta, a.Bp, a.Cv, a.P, a.nchunks, a.T, a.k, t, ldb, stream_nt, blocks_per_tile, a.dyn);
+      spmm_group_weighted_kernel<POLICY, BIG><<<dim3(nblocks), dim3(256), lds_env, s>>>(a.stream, a.vals, meta, a.Bp, a.Cv, a.P, a.nchunks, a.T, a.k, t, ldb, stream_nt, blocks_per_tile, a.dyn);
     else if (a.ring)
-      spmm_group_ring_kernel<POLICY, BIG><<<dim3(nblocks), dim3(256), 0, s>>>(a.stream, meta, a.Bp, a.Cv, a.P, a.nchunks, a.T, a.k, t, ldb, stream_nt, blocks_per_tile, a.dyn);
+      spmm_group_ring_kernel<POLICY, BIG><<<dim3(nblocks), dim3(256), lds_env, s>>>(a.stream, meta, a.Bp, a.Cv, a.P, a.nchunks, a.T, a.k, t, ldb, stream_nt, blocks_per_tile, a.dyn);
     else
-      spmm_group_kernel<POLICY, BIG><<<dim3(nblocks), dim3(256), 0, s>>>(a.stream, meta, a.Bp, a.Cv, a.P, a.nchunks, a.T, a.k, t, ldb, stream_nt, blocks_per_tile, a.dyn);
+      spmm_group_kernel<POLICY, BIG><<<dim3(nblocks), dim3(256), lds_env, s>>>(a.stream, meta, a.Bp, a.Cv, a.P, a.nchunks, a.T, a.k, t, ldb, stream_nt, blocks_per_tile, a.dyn);
   }
   return hipGetLastError();
 }
