@@ -1065,3 +1065,44 @@ def test_dense_panels_keep_non_finite_features_out_of_rows_that_do_not_reference
     Bf = B.copy(); Bf[300, 7] = 0.0; Bf[900, 50] = 0.0
     Cref = oracle_spmm(rowptr, col, val, Bf)
     assert rel_err(C[~touched], Cref[~touched]) <= TOL                     # and the clean rows are exact
+
+
+@pytest.mark.parametrize("shape", ["small", "sliced", "sliced_epilogue", "weighted"])
+def test_spmm_can_be_captured_in_a_hip_graph_and_replayed(shape):
+    """after one eager call (workspaces allocated, streams built) gcn_spmm_csr_f32 only enqueues kernels on the stream it
+    is given: the call is captured in a HIP graph (torch.cuda.CUDAGraph) and replayed on NEW operand contents — the path
+    a launch-bound training loop on a small graph takes; the sliced group kernels (partial slab, fused fix-up) too"""
+    d = _dev()
+    n, e, k = (3000, 15000, 16) if shape == "small" else (20000, 1500000, 128)
+    rowptr, col, val = sym_norm_graph(n, e, seed=11)
+    if shape == "weighted":
+        val = (val * (1.0 + 0.5 * np.random.default_rng(5).random(len(val)))).astype(np.float32)
+    adj = _adj(rowptr, col, val, n, n, **({} if shape == "small" else {"slices": 4}))
+    name = adj.main_kernel(k)
+    if shape != "small":
+        assert name.startswith("gcn::spmm_group") and (shape != "weighted" or "weighted" in name), name
+    rng = np.random.default_rng(12)
+    B0 = rng.standard_normal((n, k)).astype(np.float32)
+    B1 = rng.standard_normal((n, k)).astype(np.float32)
+    bias = rng.standard_normal(k).astype(np.float32) if shape == "sliced_epilogue" else None
+    bias_d = torch.from_numpy(bias).to(d) if bias is not None else None
+    Bd = torch.from_numpy(B0).to(d)
+    out = torch.empty((n, k), dtype=torch.float32, device=d)
+    side = torch.cuda.Stream(d)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        adj.matmul_raw(Bd, out=out, bias=bias_d, relu=bias is not None)           # eager warm-up on the capture stream
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        adj.matmul_raw(Bd, out=out, bias=bias_d, relu=bias is not None)
+    for B in (B1, B0):
+        Bd.copy_(torch.from_numpy(B))
+        out.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        ref = oracle_spmm(rowptr, col, val, B)
+        if bias is not None:
+            ref = np.maximum(ref + bias, 0)
+        assert rel_err(out.cpu().numpy(), ref) <= TOL, (shape, name)
