@@ -72,7 +72,12 @@ size_t  gcn_spmm_plan_workspace_bytes(const gcn_spmm_plan_t* plan, int32_t k);
  * to pre-zero, unlike gcn6.py:37).  Asynchronous on `stream` (NULL = the legacy
  * default stream, which is what the reference launches on, flexspmm.cu:512).
  * Deterministic: no atomics, each row is summed in CSR order within a chunk
- * and chunk partials are added in chunk order. */
+ * and chunk partials are added in chunk order.
+ * Stream capture: the first call for a width allocates the plan's workspaces
+ * (and builds the streams of a sliced plan); every later call with the same width
+ * only enqueues kernels on `stream`, so it can be captured in a HIP graph and
+ * replayed on new operand contents (tests/test_spmm_gpu.py,
+ * test_spmm_can_be_captured_in_a_hip_graph_and_replayed). */
 int gcn_spmm_csr_f32(gcn_spmm_plan_t* plan,
                      const int32_t* rowptr_dev, const int32_t* col_dev,
                      const float* val_dev, const float* B_dev, float* C_dev,
