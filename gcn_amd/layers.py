@@ -147,7 +147,9 @@ class GCN(nn.Module):
 
     def forward(self, x, adj):
         with self.dur_fwd:
-            if self.fuse_epilogue and self.training and self.dropout > 0:
+            # (under HIP-graph capture the Philox offset, a host integer, would be frozen into the graph — every replay the
+            #  same mask; torch's own dropout draws from the generator state the graph registers, so it takes over there)
+            if self.fuse_epilogue and self.training and self.dropout > 0 and not torch.cuda.is_current_stream_capturing():
                 # bias + ReLU + dropout mask in the SpMM epilogue; a fresh Philox offset per forward pass
                 if self.dropout_seed is None:
                     self.dropout_seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
@@ -210,13 +212,18 @@ class GCN(nn.Module):
         return self
 
     def fit(self, features, adj, labels, idx_train, train_iters=200, initialize=True, verbose=False,
-            normalize=True, reuse_prepared=False):
+            normalize=True, reuse_prepared=False, hip_graph=False):
+        """gcn6.fit (gcn6.py:262-410).  hip_graph=True: the training step — forward, loss, backward, Adam — is captured
+        once in a HIP graph after three eager iterations and replayed for the rest: for graphs small enough that an epoch
+        is a few dozen launch-bound kernels (Cora-, Pubmed-shaped), where the launches, not the kernels, set the pace."""
         if initialize:
             self.initialize()
         if not (reuse_prepared and self.adj is not None):   # (a second fit on the same graph keeps steps 1-4)
             self.prepare(features, adj, labels, normalize)
         idx = self._new_index[torch.as_tensor(np.asarray(idx_train)).long()].to(self.labels.device)
         self.train()
+        if hip_graph:
+            return self._fit_captured(idx, train_iters, verbose)
         opt = torch.optim.Adam(self.parameters(), lr=self.lr, weight_decay=self.weight_decay)
         ti = timers.Timers()
         losses = []
@@ -235,6 +242,46 @@ class GCN(nn.Module):
                 ti.reset()
         self.output = output
         return losses
+
+    def _fit_captured(self, idx, train_iters, verbose):
+        dev = self.labels.device
+        opt = torch.optim.Adam(self.parameters(), lr=self.lr, weight_decay=self.weight_decay, capturable=True)
+        target = self.labels[idx]
+        losses = torch.zeros(train_iters, dtype=torch.float32, device=dev)
+
+        def step():
+            output = self.forward(self.features, self.adj)
+            loss = F.nll_loss(output[idx], target)
+            loss.backward()
+            opt.step()
+            return output, loss
+
+        # eager iterations first, on the stream the capture will use: every workspace of the SpMM plans (forward and
+        # backward widths) and Adam's state exist before the capture begins
+        warm = min(3, train_iters)
+        cur = torch.cuda.current_stream(dev)
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(cur)
+        output = None
+        with torch.cuda.stream(side):
+            for i in range(warm):
+                opt.zero_grad(set_to_none=True)
+                output, loss = step()
+                losses[i] = loss.detach()
+            if train_iters > warm:
+                opt.zero_grad(set_to_none=True)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=side):
+                    output, loss = step()
+                for i in range(warm, train_iters):
+                    graph.replay()
+                    losses[i].copy_(loss.detach())
+        cur.wait_stream(side)
+        self.output = output
+        out = [float(v) for v in losses.tolist()]           # one synchronisation, at the end
+        if verbose:
+            print(f"captured fit: {train_iters} iterations ({warm} eager), loss {out[0]:.6f} -> {out[-1]:.6f}")
+        return out
 
     def timing_report(self):
         """the per-layer lines gcn6 prints after fit (gcn6.py:401-410)"""

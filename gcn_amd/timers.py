@@ -56,7 +56,8 @@ class CTimer:
 
     def start(self):
         assert self.now is None
-        if not self.on:
+        # (under HIP-graph capture events can neither be queried nor timed: the interval is counted, not measured)
+        if not self.on or torch.cuda.is_current_stream_capturing():
             self.now = ()
             return self
         self.harvest()
@@ -68,7 +69,7 @@ class CTimer:
     def stop(self):
         assert self.now is not None
         self.n_calls += 1
-        if self.on:
+        if self.on and self.now:
             self.now[1].record()
             self.pending.append(self.now)
         self.now = None

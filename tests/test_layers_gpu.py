@@ -71,18 +71,20 @@ def test_training_reduces_the_loss_and_timers_report():
 
 @pytest.mark.parametrize("dataset", ["pubmed", "reddit"])       # Â(XW) for layer 2 (as gcn1) / (ÂX)W (gcn6.py:214-218)
 @pytest.mark.parametrize("fused", [False, True])
-def test_training_trajectory_matches_the_python_reference(dataset, fused):
+@pytest.mark.parametrize("hip_graph", [False, True])           # the training step captured in a HIP graph and replayed
+def test_training_trajectory_matches_the_python_reference(dataset, fused, hip_graph):
     """forward + backward THROUGH THE OP + epilogue backward + Adam, composed: the loss of every epoch and the final
     log-probabilities of pygcn.gcn1.GCN.fit (gcn1.py:132-217; 20 epochs, dropout 0, recorded by
     oracle/make_golden.py from the reference itself) are reproduced from the same initial weights — to 1e-4
-    relative on the losses and 1e-4 on the outputs, both layer orders, fused and unfused epilogue."""
+    relative on the losses and 1e-4 on the outputs, both layer orders, fused and unfused epilogue, eager and with the
+    step captured in a HIP graph (GCN.fit(hip_graph=True): three eager iterations, the rest replayed)."""
     g, n, raw, X = _golden_problem()
     t = np.load(os.path.join(GOLDEN, "gcn1_train_cora_shaped.npz"))
     model = gcn_amd.GCN(int(g["nfeat"]), int(g["nhid"]), int(g["ncls"]), dataset=dataset, device="cuda:0", order=None,
                         dropout=float(t["dropout"]), lr=float(t["lr"]), weight_decay=float(t["weight_decay"]),
                         fuse_epilogue=fused).to("cuda:0")
     _load_weights(model, t)                                    # the reference's initial weights (seed 15)
-    losses = model.fit(X, raw, t["labels"], t["idx_train"], train_iters=int(t["epochs"]), initialize=False)
+    losses = model.fit(X, raw, t["labels"], t["idx_train"], train_iters=int(t["epochs"]), initialize=False, hip_graph=hip_graph)
     ref = t["losses"]
     assert len(losses) == len(ref)
     assert float(np.max(np.abs(np.asarray(losses) - ref) / ref)) <= 1e-4, (losses, ref)
@@ -223,3 +225,30 @@ def test_prepare_measures_sliced_against_unsliced_on_a_renumbered_graph(n):
     again = model.adj.autotune(k=128, reps=5)              # re-time: the choice holds up
     assert model.tuning[best] <= 1.03 * min(model.tuning.values())
     assert again[model.adj.num_slices] <= 1.03 * min(again.values())
+
+
+def test_captured_fit_draws_a_fresh_dropout_mask_every_replay_and_is_faster_than_the_eager_loop():
+    """GCN.fit(hip_graph=True) with dropout: the mask comes from torch's generator (the graph registers its state), so the
+    losses of consecutive replays differ the way eager epochs differ, training still converges, and on a Cora-shaped
+    graph — an epoch of a few dozen launch-bound kernels — the replayed loop is faster than the eager one"""
+    import time
+    g, n, raw, X = _golden_problem()
+    t = np.load(os.path.join(GOLDEN, "gcn1_train_cora_shaped.npz"))
+    secs = {}
+    for hip_graph in (False, True):
+        torch.manual_seed(3)
+        model = gcn_amd.GCN(int(g["nfeat"]), int(g["nhid"]), int(g["ncls"]), dataset="pubmed", device="cuda:0", order=None,
+                            dropout=0.5, lr=0.01, weight_decay=5e-4, fuse_epilogue=True).to("cuda:0")
+        _load_weights(model, t)
+        model.fit(X, raw, t["labels"], t["idx_train"], train_iters=5, initialize=False, hip_graph=hip_graph)     # (warm)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        losses = model.fit(X, raw, t["labels"], t["idx_train"], train_iters=200, initialize=False, reuse_prepared=True,
+                           hip_graph=hip_graph)
+        torch.cuda.synchronize()
+        secs[hip_graph] = time.perf_counter() - t0
+        assert len(losses) == 200 and all(np.isfinite(losses))
+        assert len({round(v, 6) for v in losses[3:40]}) > 30          # fresh masks: no two epochs alike
+        assert np.mean(losses[-20:]) < 0.8 * np.mean(losses[:5])      # and it learns
+    assert secs[True] < secs[False], secs
+    print("fit 200 epochs: eager %.3f s, captured %.3f s" % (secs[False], secs[True]))

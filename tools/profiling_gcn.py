@@ -28,6 +28,8 @@ def main():
     ap.add_argument("-i", "--train-iters", dest="train_iters", type=int, default=100)
     ap.add_argument("--order", default="none", choices=["none", "dfs", "gorder", "rabbit", "rcm", "deg", "communities"])
     ap.add_argument("--fuse", action="store_true", help="bias + ReLU in the SpMM epilogue")
+    ap.add_argument("--hip-graph", dest="hip_graph", action="store_true",
+                    help="capture the training step in a HIP graph and replay it (small graphs: launch-bound epochs)")
     ap.add_argument("--layer-order", default="reference", choices=["reference", "auto"],
                     help="layer 2 as the reference hard-codes it per dataset, or with the SpMM at the narrower width")
     ap.add_argument("--warmup-iters", type=int, default=3, help="untimed iterations before the timed ones (0: as the reference)")
@@ -68,7 +70,8 @@ def main():
         model.reset_timing()
         t0 = time.time()
     losses = model.fit(features, adj, labels, idx_train, train_iters=args.train_iters, verbose=True,
-                       normalize=normalize, initialize=args.warmup_iters == 0, reuse_prepared=args.warmup_iters > 0)
+                       normalize=normalize, initialize=args.warmup_iters == 0, reuse_prepared=args.warmup_iters > 0,
+                       hip_graph=args.hip_graph)
     torch.cuda.synchronize()
     print(f"fit: {time.time() - t0:.2f} s, loss {losses[0]:.4f} -> {losses[-1]:.4f}, "
           f"slices={model.adj.num_slices} chunks={model.adj.num_chunks}x{model.adj.chunk_size}")
