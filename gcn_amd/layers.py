@@ -240,11 +240,16 @@ class GCN(nn.Module):
                 print(f"Epoch {i:3d}, training loss: {losses[-1]:.6f}  Fwd: {ti.h.fwd.avms():.3f} ms/iter"
                       f"  Bwd: {ti.h.bwd.avms():.3f} ms/iter")
                 ti.reset()
-        self.output = output
-        return losses
+        self.output = output.detach()       # (detached: a live autograd graph would keep this run's AccumulateGrad nodes —
+        return losses                       #  and the stream they were made on — alive into the next fit, see _fit_captured)
 
     def _fit_captured(self, idx, train_iters, verbose):
         dev = self.labels.device
+        # Nothing may keep an autograd graph of an earlier (eager, default-stream) run alive: its AccumulateGrad nodes would
+        # be reused, and their work on the default stream inside the capture is what hipStreamEndCapture dies of.
+        self.output = None
+        for p_ in self.parameters():
+            p_.grad = None
         opt = torch.optim.Adam(self.parameters(), lr=self.lr, weight_decay=self.weight_decay, capturable=True)
         target = self.labels[idx]
         losses = torch.zeros(train_iters, dtype=torch.float32, device=dev)
@@ -277,7 +282,7 @@ class GCN(nn.Module):
                     graph.replay()
                     losses[i].copy_(loss.detach())
         cur.wait_stream(side)
-        self.output = output
+        self.output = output.detach() if output is not None else None
         out = [float(v) for v in losses.tolist()]           # one synchronisation, at the end
         if verbose:
             print(f"captured fit: {train_iters} iterations ({warm} eager), loss {out[0]:.6f} -> {out[-1]:.6f}")
