@@ -160,8 +160,8 @@ slice_reduce_kernel(const float* __restrict__ Cv, float* __restrict__ C,
   }
 }
 
-// The same reduction for row widths that divide 256 floats (k = 4 .. 256, the widths of the 64-column tiles):
-// a wave covers 1 KiB of C at a time — 256 / k consecutive rows, every lane a float4 — so all 64 lanes load
+// The same reduction for row widths up to 256 floats (k % 4 == 0; the widths of the 64-column tiles and the padded odd ones):
+// a wave covers up to 1 KiB of C at a time — floor(256 / k) consecutive rows, every lane a float4 — so (nearly) all 64 lanes load
 // whatever k is (the kernel above leaves half of them idle at k = 128), and the S partial rows are fetched
 // eight at a time with non-temporal loads (they are read exactly once) before they are added in slice order.
 typedef float slice_f32x4 __attribute__((ext_vector_type(4)));
@@ -180,8 +180,9 @@ slice_reduce_wide_kernel(const float* __restrict__ Cv, float* __restrict__ C,
   const int lane = threadIdx.x & 63;
   const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const long long nw = (long long)gridDim.x * 4;
-  const int rpw = 256 / k;                            // rows per wave and step
+  const int rpw = 256 / k;                            // rows per wave and step (k = 48: five rows on sixty lanes)
   const int lr = lane * 4 / k, x = lane * 4 % k;
+  if (lr >= rpw) return;                              // (widths that do not divide 256 floats leave the last lanes without a row)
   const size_t slab = (size_t)m * (size_t)k;          // floats between two slices' partial rows of one row
   const char* const Cvb = reinterpret_cast<const char*>(Cv);
   const char* const Pb = reinterpret_cast<const char*>(cuts.P);
@@ -306,8 +307,8 @@ hipError_t launch_slice_reduce(const float* Cv, float* C, const float* bias, int
   int nb = (m + 3) / 4;
   if (nb > 8192) nb = 8192;
   const uintptr_t al = (uintptr_t)Cv | (uintptr_t)C | (uintptr_t)bias | (uintptr_t)cuts.P;
-  if (k % 4 == 0 && 256 % k == 0 && (al & 15) == 0) {
-    const long long steps = ((long long)m * k + 255) / 256;      // wave steps of 1 KiB
+  if (k % 4 == 0 && k <= 256 && (al & 15) == 0) {
+    const long long steps = ((long long)m + 256 / k - 1) / (256 / k);   // wave steps of 256 / k rows (1 KiB when k divides 256)
     static const int cap_env = [] { const char* e = getenv("GCN_AMD_REDUCE_BLOCKS"); return e ? atoi(e) : 0; }();   // development knob
     const int cap = cap_env > 0 ? cap_env : 16384;
     const int nbw = (int)(steps / 4 + 1 < cap ? steps / 4 + 1 : cap);
