@@ -920,8 +920,12 @@ int gcn_spmm_plan_main_kernel(const gcn_spmm_plan_t* p, int32_t k, int32_t epilo
   const bool big = gcn::spmm_group_needs_big(group_table_rows(p), ld_eff);
   const char* bigs = big ? "true" : "false";
   if (a.valless && group_pass(p)) {
+    gcn::GroupArgs probe{};
+    probe.k = a.k; probe.ldb = ld_eff; probe.table_rows = group_table_rows(p); probe.ring = gcn::group_ring() ? 1 : 0;
     if (gcn::group8_enabled() && a.k <= 32 && p->group.nchunks % 64 == 0)
       snprintf(buf, (size_t)buflen, "gcn::spmm_group8_kernel<%s, %s>", gcn::group_ring() ? "true" : "false", bigs);
+    else if (gcn::spmm_group12_applies(probe))
+      snprintf(buf, (size_t)buflen, "gcn::spmm_group12_kernel");
     else
       snprintf(buf, (size_t)buflen, "gcn::spmm_group%s_kernel<%d, %s>", gcn::group_ring() ? "_ring" : "", big ? 2 : gcn::group_store(), bigs);
     return GCN_OK;

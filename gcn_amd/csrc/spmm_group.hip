@@ -466,6 +466,151 @@ spmm_group8_weighted_kernel(const unsigned short* __restrict__ stream, const flo
   group8_walk<false, true, BIG>(stream, vals, chunk_meta, Bp, Cv, P, nchunks, T, k, ldb, stream_nt, dyn);
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// 33 <= k <= 48: FIVE 12-lane row engines per wave (lane = g*12 + f, f = which float4 of the 48-column row; lanes 60..63
+// idle).  The addressers charge a gather instruction for its 64 lane addresses whatever they fetch (gather_x3_probe), so
+// a row of 192 bytes occupies 12 lanes here, not 16 with four of them idle: five rows per instruction instead of four.
+// (Worth 4-7 % of the whole SpMM, not the 20 % the instruction count suggests: a 192-byte row still arrives as two
+// whole 128-byte lines, and at 64 B/clk per CU five rows of two lines cost the L2 -> L1 path 20 clocks where four cost
+// 16 — with 16 lanes x 16 bytes the address rate and the line rate bind together)
+// SAME stream as the 16-lane kernel (blocks of 16 entries, runs of 64 stored lane-major): lane f < 12 holds entry f of
+// its group's block, lanes f < 4 hold entries 12..15 as well (a second 8-byte word per run); an entry reaches the
+// group's lanes through ds_bpermute (a DPP row is 16 lanes wide and would straddle the groups).  Row ends: two ballots
+// (entries 0..11 and 12..15).  Same chunk_meta, partial slab, cut lists and pieces; a wave owns five consecutive
+// chunks, a block twenty.  Value-free pass, 32-bit slice bases, LDS ring of five rows per group (one 60-lane store).
+__device__ __forceinline__ int lane_bcast(int src_lane_bytes, int v) { return __builtin_amdgcn_ds_bpermute(src_lane_bytes, v); }
+
+__device__ __forceinline__ void
+group12_walk(const unsigned short* __restrict__ stream, const int2* __restrict__ chunk_meta,
+             const float* __restrict__ Bp, float* __restrict__ Cv, float* __restrict__ P,
+             int nchunks, int T, int k, int ldb, int stream_nt, const int* __restrict__ dyn) {
+  if (dyn) { if (dyn[0] == 0) return; nchunks = dyn[1]; }
+  const int lane = threadIdx.x & 63;
+  const int wib  = threadIdx.x >> 6;
+  const int g    = lane / 12;                                   // 0..4; 5: the four spare lanes
+  const int f    = lane - g * 12;
+  const int per_xcd = nchunks >> 3;
+  const int bx = (int)blockIdx.x;
+  const int c_w = ((bx >> 3) * 4 + wib) * 5;                    // first chunk of this wave inside its XCD's range
+  if (c_w >= per_xcd) return;                                   // (whole wave)
+  // groups past the XCD's range and the spare lanes walk the wave's first chunk along (loads only, nothing stored)
+  const bool live = g < 5 && c_w + g < per_xcd;
+  const int c = (bx & 7) * per_xcd + (live ? c_w + g : c_w);
+
+  const int fcol = f * 4;
+  const bool fok = live && fcol < k;
+  const unsigned row_bytes = (unsigned)ldb * 4u;
+  const unsigned foff = (unsigned)(fcol < k ? fcol : 0) * 4u;
+  const char* Bb = reinterpret_cast<const char*>(Bp);
+  const size_t kk = (size_t)k;
+
+  const int2 meta = chunk_meta[c];
+  const int vrow = meta.x >> 1;
+  const bool head = meta.x & 1;
+  const int base = meta.y;
+  float* ptr  = head ? P + (size_t)(2 * c) * kk + fcol : Cv + (size_t)vrow * kk + fcol;
+  float* nptr = Cv + (size_t)(vrow + 1) * kk + fcol;
+  bool first = true;
+  __shared__ f32x4 ring[4][5][5][12];                           // [wave][group][slot][float4 of the row]
+  int ring_n = 0;
+  float* ring_base = nullptr;
+  const int row_l = lane / 12;                                  // which ring row this lane writes out in a drain (== g)
+#define GCN_G12_DRAIN(G2, ROWS)                                                                     \
+  {                                                                                                 \
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(uintptr_t)ring_base, 12 * G2);    \
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)((uintptr_t)ring_base >> 32), 12 * G2); \
+    float* b0 = reinterpret_cast<float*>(((uintptr_t)hi << 32) | lo);                              \
+    if (row_l < (ROWS) && fcol < k) {                                                               \
+      const f32x4 rv = ring[wib][G2][row_l][f];                                                     \
+      store_row_piece<2>(b0 + (size_t)row_l * kk + fcol, make_float4(rv.x, rv.y, rv.z, rv.w));      \
+    }                                                                                               \
+    if (g == G2) ring_n = 0;                                                                        \
+  }
+
+  typedef unsigned int u32x2_g __attribute__((ext_vector_type(2)));
+  const u32x2_g* __restrict__ sp = reinterpret_cast<const u32x2_g*>(stream + (size_t)c * T);
+  const int f2 = f < 4 ? 12 + f : f;                            // the second word of lanes 0..3: entries 12..15 (others: a copy)
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  u32x2_g eq = stream_nt ? __builtin_nontemporal_load(sp + f) : sp[f], eq_nx = eq;
+  u32x2_g eq2 = stream_nt ? __builtin_nontemporal_load(sp + f2) : sp[f2], eq2_nx = eq2;
+  const int srcA = g * 48;                                      // byte index of the group's lane 0 (ds_bpermute counts bytes)
+  unsigned long long endsA = 0ull, endsB = 0ull;
+#pragma unroll 1
+  for (int blk = 0; blk < T / 16; ++blk) {
+    const int j = blk & 3;
+    if (j == 0 && blk + 4 < T / 16) {
+      const int nx = (blk / 4 + 1) * 16;
+      eq_nx = stream_nt ? __builtin_nontemporal_load(sp + nx + f) : sp[nx + f];
+      eq2_nx = stream_nt ? __builtin_nontemporal_load(sp + nx + f2) : sp[nx + f2];
+    }
+    const unsigned e  = ((j & 2 ? eq.y : eq.x) >> (16 * (j & 1))) & 0xFFFFu;
+    const unsigned e2 = ((j & 2 ? eq2.y : eq2.x) >> (16 * (j & 1))) & 0xFFFFu;
+    if (j == 3) { eq = eq_nx; eq2 = eq2_nx; }
+    const int rowoff  = (int)(__umul24((e & 0x7FFFu) + (unsigned)base, row_bytes));
+    const int rowoff2 = (int)(__umul24((e2 & 0x7FFFu) + (unsigned)base, row_bytes));
+    float4 b[16];
+#define GCN_G12_ALL(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15)
+#define GCN_G12_GATHER(UU) \
+    b[UU] = *reinterpret_cast<const float4*>(Bb + (size_t)((unsigned)lane_bcast(srcA + 4 * (UU < 12 ? UU : UU - 12), UU < 12 ? rowoff : rowoff2) + foff));
+    GCN_G12_ALL(GCN_G12_GATHER)
+#undef GCN_G12_GATHER
+    endsA = __ballot((e >> 15) != 0);                           // bit g*12+u: entry u < 12 of group g ends a row
+    endsB = __ballot((e2 >> 15) != 0 && f < 4);                 // bit g*12+u-12: entry u >= 12
+    if ((endsA | endsB) == 0ull) {
+#define GCN_G12_ADD(UU) acc.x += b[UU].x; acc.y += b[UU].y; acc.z += b[UU].z; acc.w += b[UU].w;
+      GCN_G12_ALL(GCN_G12_ADD)
+    } else {
+      const unsigned long long mineA = endsA >> (g < 5 ? g * 12 : 60);    // this lane's group's bits at 0..11
+      const unsigned long long mineB = endsB >> (g < 5 ? g * 12 : 60);    // ... entries 12..15 at 0..3
+#define GCN_G12_STEP(UU)                                                                            \
+      GCN_G12_ADD(UU)                                                                               \
+      if ((UU < 12 ? endsA : endsB) & (0x0001001001001001ull << (UU < 12 ? UU : UU - 12))) {        \
+        if (((UU < 12 ? mineA : mineB) >> (UU < 12 ? UU : UU - 12)) & 1ull) {                       \
+          if (!(first && head) && ring_n < 5) {                                                     \
+            if (fok) ring[wib][g < 5 ? g : 0][ring_n][f] = f32x4{acc.x, acc.y, acc.z, acc.w};       \
+            if (ring_n == 0) ring_base = ptr;                                                       \
+            ++ring_n;                                                                               \
+          } else if (fok) store_row_piece<2>(ptr, acc);                                             \
+          acc = make_float4(0.f, 0.f, 0.f, 0.f);                                                    \
+          ptr = nptr; nptr += kk; first = false;                                                    \
+        }                                                                                           \
+      }
+      GCN_G12_ALL(GCN_G12_STEP)
+#undef GCN_G12_STEP
+#undef GCN_G12_ADD
+      const unsigned long long full = __ballot(ring_n == 5 && live);
+      if (full) {
+        if (full & (1ull << 0))  GCN_G12_DRAIN(0, 5)
+        if (full & (1ull << 12)) GCN_G12_DRAIN(1, 5)
+        if (full & (1ull << 24)) GCN_G12_DRAIN(2, 5)
+        if (full & (1ull << 36)) GCN_G12_DRAIN(3, 5)
+        if (full & (1ull << 48)) GCN_G12_DRAIN(4, 5)
+      }
+    }
+#undef GCN_G12_ALL
+  }
+  {
+    const unsigned long long some = __ballot(ring_n > 0 && live);
+    if (some & (1ull << 0))  GCN_G12_DRAIN(0, __builtin_amdgcn_readlane(ring_n, 0))
+    if (some & (1ull << 12)) GCN_G12_DRAIN(1, __builtin_amdgcn_readlane(ring_n, 12))
+    if (some & (1ull << 24)) GCN_G12_DRAIN(2, __builtin_amdgcn_readlane(ring_n, 24))
+    if (some & (1ull << 36)) GCN_G12_DRAIN(3, __builtin_amdgcn_readlane(ring_n, 36))
+    if (some & (1ull << 48)) GCN_G12_DRAIN(4, __builtin_amdgcn_readlane(ring_n, 48))
+  }
+#undef GCN_G12_DRAIN
+  // the row piece that sticks out of the chunk's end: the chunk's last entry is entry 15 of its last block (lane 3's second word)
+  if (!((endsB >> (g < 5 ? g * 12 + 3 : 63)) & 1ull)) {
+    if (fok) store_row_piece<2>(ptr, acc);
+  }
+}
+
+__global__ void __launch_bounds__(256)
+spmm_group12_kernel(const unsigned short* __restrict__ stream, const int2* __restrict__ chunk_meta,
+                    const float* __restrict__ Bp, float* __restrict__ Cv, float* __restrict__ P,
+                    int nchunks, int T, int k, int ldb, int stream_nt, const int* __restrict__ dyn) {
+  group12_walk(stream, chunk_meta, Bp, Cv, P, nchunks, T, k, ldb, stream_nt, dyn);
+}
+
 // 32-bit byte offsets (entry + slice base) * row_bytes reach every row of the sliced copy?  (__umul24: both factors
 // below 2^24, and the product below 2^32.)  Otherwise the BIG variants add the slice base in 64 bits.
 bool spmm_group_needs_big(long long table_rows, int ldb) {
@@ -481,6 +626,13 @@ bool spmm_group_eligible(int k, int ldb, long long table_rows, const void* B, co
   if (!(k % 4 == 0 && ldb % 4 == 0 && (al & 15) == 0 && ldb * 4 < (1 << 24))) return false;
   // BIG: the offset inside a slice (< 32 768 rows) must still fit 32 bits
   return !spmm_group_needs_big(table_rows, ldb) || ldb * 4 < (1 << 17);
+}
+
+// 33 <= k <= 48, value-free, 32-bit slice bases: the five-engine kernel (GCN_AMD_GROUP12=0: the 64-column pass)
+bool spmm_group12_applies(const GroupArgs& a) {
+  static const bool on = [] { const char* e = getenv("GCN_AMD_GROUP12"); return !e || e[0] != '0'; }();
+  const int ldb = a.ldb > 0 ? a.ldb : a.k;
+  return on && a.narrow12 && !a.vals && a.ring && a.k > 32 && a.k <= 48 && a.k % 4 == 0 && !spmm_group_needs_big(a.table_rows, ldb);
 }
 
 // k <= 32, whole waves of eight chunks per XCD: the eight-engine kernels take the launch
@@ -538,6 +690,14 @@ hipError_t launch_spmm_group(const GroupArgs& a, hipStream_t s) {
   const bool big = spmm_group_needs_big(a.table_rows, ldb);
   if (big && ldb * 4 >= (1 << 17)) return hipErrorInvalidValue;
   if (spmm_group8_applies(a)) return big ? launch_group8_t<true>(a, ldb, s) : launch_group8_t<false>(a, ldb, s);
+  if (spmm_group12_applies(a)) {
+    const int per_xcd = a.nchunks / 8;
+    const int nb12 = 8 * ((per_xcd + 19) / 20);
+    const int stream_nt12 = (size_t)a.nchunks * (size_t)a.T * 2u > ((size_t)64 << 20) ? 1 : 0;
+    spmm_group12_kernel<<<dim3(nb12), dim3(256), 0, s>>>(a.stream, reinterpret_cast<const int2*>(a.chunk_meta), a.Bp, a.Cv, a.P,
+                                                         a.nchunks, a.T, a.k, ldb, stream_nt12, a.dyn);
+    return hipGetLastError();
+  }
   if (big) return launch_group_tp<2, true>(a, ldb, s);               // (the store policy is a tuning knob: BIG keeps the default)
   if (a.store_policy == 1) return launch_group_tp<1, false>(a, ldb, s);
   if (a.store_policy == 2) return launch_group_tp<2, false>(a, ldb, s);

@@ -82,6 +82,7 @@ struct GroupArgs {
   long long table_rows = 0;      // rows of Bp, S * (w + 1): decides 32-bit or 64-bit (BIG) slice-base addressing
   int store_policy = 2;          // partial-row stores: 0 plain, 1 sc1 (write-through), 2 nt (streaming)
   int narrow8 = 1;               // k <= 32 on the eight-engine kernel (spmm_group8_kernel) when nchunks % 64 == 0
+  int narrow12 = 1;              // 33 <= k <= 48, value-free: the five-engine kernel (spmm_group12_kernel)
   int merge_tiles = 1;           // every 64-column tile in one launch (tile t+1 fills the CUs tile t's tail leaves idle)
   int ring = 1;                  // value-free pass: finished rows leave through the LDS ring, four at a time (spmm_group_ring_kernel)
 };
@@ -89,6 +90,7 @@ bool spmm_group_eligible(int k, int ldb, long long table_rows, const void* B, co
 bool spmm_group_needs_big(long long table_rows, int ldb);
 hipError_t launch_spmm_group(const GroupArgs& a, hipStream_t s);
 bool spmm_group8_applies(const GroupArgs& a);
+bool spmm_group12_applies(const GroupArgs& a);
 // the slice-major 15-bit stream the group kernel walks (S slices of width w = ceil(n/S) <= 32767): every virtual
 // row gets >= 1 entry, every slice is padded to whole chunks and the total to a multiple of 32 chunks with
 // entries that gather the slice's zero row.  Outputs: vrowptr_g [S*m+1] (caller-allocated; the fix-up pass needs

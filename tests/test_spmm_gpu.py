@@ -980,7 +980,8 @@ def test_narrow_widths_on_the_eight_engine_kernel(S):
         assert torch.equal(C, adj.matmul_raw(Bd))
         Ce = adj.matmul_raw(Bd, bias=torch.from_numpy(bias).to(_dev()), relu=True).cpu().numpy()
         assert rel_err(Ce, np.maximum(Cref + bias, 0)) <= TOL, k
-    assert adj.main_kernel(36).startswith("gcn::spmm_group_ring_kernel<")
+    assert adj.main_kernel(36) in ("gcn::spmm_group12_kernel", "gcn::spmm_group_ring_kernel<2, false>")   # (GCN_AMD_GROUP12=0: the latter)
+    assert adj.main_kernel(52).startswith("gcn::spmm_group_ring_kernel<")
     assert not adj.main_kernel(8).startswith("gcn::spmm_group")
 
 

@@ -97,6 +97,32 @@ def test_group8_kernel_random(seed):
     assert rel_err(Ce, np.maximum(ref + bias, 0)) <= TOL, (seed, n, S, k, name)
 
 
+@pytest.mark.parametrize("seed", range(24))
+def test_group12_kernel_random(seed):
+    """33 <= k <= 48 on a value-free sliced plan: five 12-lane row engines per wave (spmm_group12_kernel) on the SAME stream
+    as the 16-lane kernel — entries through ds_bpermute, two row-end ballots, a ring of five rows per group; odd widths
+    ride the k' detour into it; ragged graphs (empty rows, rows longer than a chunk), several slice counts"""
+    n, rowptr, col, val, rng = _graph(seed + 200)
+    d = torch.device("cuda:0")
+    S = int(rng.choice([2, 3, 4, 8, 15]))
+    k = int(rng.choice([33, 36, 37, 40, 41, 44, 45, 47, 48]))
+    adj = gcn_amd.CsrAdjacency(torch.from_numpy(rowptr).to(d), torch.from_numpy(col).to(d), torch.from_numpy(val).to(d),
+                               (n, n), slices=S)
+    assert adj.num_slices == S and adj.has_value_factors
+    name = adj.main_kernel(k)
+    if len(col) // n >= 48 and os.environ.get("GCN_AMD_GROUP12", "1") != "0":      # (below: the weighted pass, see valless_pays)
+        assert name == "gcn::spmm_group12_kernel", (name, k)
+    B = rng.standard_normal((n, k)).astype(np.float32)
+    ref = oracle_spmm(rowptr, col, val, B)
+    Bd = torch.from_numpy(B).to(d)
+    C = adj.matmul_raw(Bd)
+    assert rel_err(C.cpu().numpy(), ref) <= TOL, (seed, n, S, k, name)
+    assert torch.equal(C, adj.matmul_raw(Bd))
+    bias = rng.standard_normal(k).astype(np.float32)
+    Ce = adj.matmul_raw(Bd, bias=torch.from_numpy(bias).to(d), relu=True).cpu().numpy()
+    assert rel_err(Ce, np.maximum(ref + bias, 0)) <= TOL, (seed, n, S, k, name)
+
+
 def _big_child():
     """runs in a child process with GCN_AMD_GROUP_BIG=1 (the knob is read once per process): every group kernel in
     its 64-bit slice-base variant — what tables of 4 GiB and more get — against the fp64 oracle"""
