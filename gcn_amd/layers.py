@@ -45,7 +45,8 @@ class _FusedSpmmBiasRelu(torch.autograd.Function):
         if ctx.relu:
             g = g * (out > 0)                          # (dropped elements are 0 in `out`, and their gradient is 0 already)
         g = g.contiguous()
-        return None, ctx.adj.transpose().matmul_raw(g), (g.sum(0) if ctx.has_bias else None), None, None
+        gx = ctx.adj.transpose().matmul_raw(g) if ctx.needs_input_grad[1] else None
+        return None, gx, (g.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None), None, None
 
 
 class _Layer(nn.Module):

@@ -342,6 +342,8 @@ class _SpmmFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_out):
+        if not ctx.needs_input_grad[1]:                # (a constant operand, e.g. the input features: no Âᵀ·grad to compute)
+            return None, None
         return None, ctx.adj.transpose().matmul_raw(grad_out.contiguous())
 
 

@@ -252,3 +252,28 @@ def test_captured_fit_draws_a_fresh_dropout_mask_every_replay_and_learns():
     # (no assertion on the times: the capture itself — instantiating the graph — is part of the captured fit and varies
     #  between 0.05 and 0.25 s from run to run; tools/profiling_gcn.py --hip-graph is where the two loops are compared)
     print("fit 200 epochs: eager %.3f s, captured %.3f s (capture included)" % (secs[False], secs[True]))
+
+
+def test_backward_skips_the_transposed_spmm_for_an_operand_that_needs_no_gradient():
+    """(ÂX)·W with constant input features X: autograd asks the op for no gradient with respect to X, and the op does not
+    compute one — the backward pass of that layer costs no SpMM at all; with X requiring a gradient it costs one"""
+    g, n, raw, X = _golden_problem()
+    model = gcn_amd.GCN(int(g["nfeat"]), int(g["nhid"]), int(g["ncls"]), device="cuda:0", order=None).to("cuda:0")
+    model.prepare(X, raw, np.zeros(n, dtype=np.int64))
+    adj, feats = model.adj, model.features
+    W = torch.randn(feats.shape[1], 8, device="cuda:0", requires_grad=True)
+    calls = []
+    raw_matmul = adj.matmul_raw
+    adj.matmul_raw = lambda *a, **kw: (calls.append(1), raw_matmul(*a, **kw))[1]
+    try:
+        for needs in (False, True):
+            x = feats.clone().requires_grad_(needs)
+            calls.clear()
+            y = (gcn_amd.spmm(adj, x) @ W).square().sum()
+            assert len(calls) == 1
+            y.backward()
+            assert len(calls) == (2 if needs else 1), (needs, len(calls))
+            assert (x.grad is not None) == needs and W.grad is not None
+            W.grad = None
+    finally:
+        adj.matmul_raw = raw_matmul
