@@ -72,7 +72,8 @@ def test_training_reduces_the_loss_and_timers_report():
 @pytest.mark.parametrize("dataset", ["pubmed", "reddit"])       # Â(XW) for layer 2 (as gcn1) / (ÂX)W (gcn6.py:214-218)
 @pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("hip_graph", [False, True])           # the training step captured in a HIP graph and replayed
-def test_training_trajectory_matches_the_python_reference(dataset, fused, hip_graph):
+@pytest.mark.parametrize("precompute_ax", [False, True])       # layer 1 as (ÂX)·W1 with ÂX aggregated once
+def test_training_trajectory_matches_the_python_reference(dataset, fused, hip_graph, precompute_ax):
     """forward + backward THROUGH THE OP + epilogue backward + Adam, composed: the loss of every epoch and the final
     log-probabilities of pygcn.gcn1.GCN.fit (gcn1.py:132-217; 20 epochs, dropout 0, recorded by
     oracle/make_golden.py from the reference itself) are reproduced from the same initial weights — to 1e-4
@@ -82,7 +83,7 @@ def test_training_trajectory_matches_the_python_reference(dataset, fused, hip_gr
     t = np.load(os.path.join(GOLDEN, "gcn1_train_cora_shaped.npz"))
     model = gcn_amd.GCN(int(g["nfeat"]), int(g["nhid"]), int(g["ncls"]), dataset=dataset, device="cuda:0", order=None,
                         dropout=float(t["dropout"]), lr=float(t["lr"]), weight_decay=float(t["weight_decay"]),
-                        fuse_epilogue=fused).to("cuda:0")
+                        fuse_epilogue=fused, precompute_ax=precompute_ax).to("cuda:0")
     _load_weights(model, t)                                    # the reference's initial weights (seed 15)
     losses = model.fit(X, raw, t["labels"], t["idx_train"], train_iters=int(t["epochs"]), initialize=False, hip_graph=hip_graph)
     ref = t["losses"]
@@ -277,3 +278,26 @@ def test_backward_skips_the_transposed_spmm_for_an_operand_that_needs_no_gradien
             W.grad = None
     finally:
         adj.matmul_raw = raw_matmul
+
+
+def test_precomputed_first_aggregation_leaves_two_spmms_per_epoch():
+    """GCN(precompute_ax=True): ÂX once, then an epoch runs the layer-2 SpMM forward and backward and nothing else
+    (four SpMMs per epoch without it), and predict() agrees with the model that aggregates every time"""
+    g, n, raw, X = _golden_problem()
+    t = np.load(os.path.join(GOLDEN, "gcn1_train_cora_shaped.npz"))
+    outs = {}
+    for pre in (False, True):
+        model = gcn_amd.GCN(int(g["nfeat"]), int(g["nhid"]), int(g["ncls"]), dataset="pubmed", device="cuda:0", order=None,
+                            dropout=0.0, lr=0.01, weight_decay=5e-4, precompute_ax=pre).to("cuda:0")
+        _load_weights(model, t)
+        model.prepare(X, raw, t["labels"])
+        calls = []
+        raw_matmul = model.adj.matmul_raw
+        model.adj.matmul_raw = lambda *a, **kw: (calls.append(1), raw_matmul(*a, **kw))[1]
+        try:
+            model.fit(X, raw, t["labels"], t["idx_train"], train_iters=5, initialize=False, reuse_prepared=True)
+        finally:
+            model.adj.matmul_raw = raw_matmul
+        assert len(calls) == (1 + 2 * 5 if pre else 4 * 5), (pre, len(calls))
+        outs[pre] = model.predict().cpu().numpy()
+    assert rel_err(outs[True], outs[False]) <= 1e-4

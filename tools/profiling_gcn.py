@@ -28,6 +28,8 @@ def main():
     ap.add_argument("-i", "--train-iters", dest="train_iters", type=int, default=100)
     ap.add_argument("--order", default="none", choices=["none", "dfs", "gorder", "rabbit", "rcm", "deg", "communities"])
     ap.add_argument("--fuse", action="store_true", help="bias + ReLU in the SpMM epilogue")
+    ap.add_argument("--precompute-ax", dest="precompute_ax", action="store_true",
+                    help="layer 1 as (AX)W with AX aggregated once (X is constant): two SpMMs per epoch instead of four")
     ap.add_argument("--hip-graph", dest="hip_graph", action="store_true",
                     help="capture the training step in a HIP graph and replay it (small graphs: launch-bound epochs)")
     ap.add_argument("--layer-order", default="reference", choices=["reference", "auto"],
@@ -59,7 +61,7 @@ def main():
     nclass = int(labels.max()) + 1
     model = gcn_amd.GCN(nfeat=features.shape[1], nhid=args.hidden, nclass=nclass, dataset=args.graph,
                         device="cuda:0", order=None if args.order == "none" else args.order,
-                        fuse_epilogue=args.fuse, layer_order=args.layer_order).to("cuda:0")
+                        fuse_epilogue=args.fuse, layer_order=args.layer_order, precompute_ax=args.precompute_ax).to("cuda:0")
     t0 = time.time()
     if args.warmup_iters > 0:
         # the reference averages its timers over every call including the first (library initialisation,
