@@ -231,6 +231,7 @@ size_t ws_elems(const gcn_spmm_plan* p, int k) {
   int chunks = std::max(p->nchunks, p->panels.out_nchunks);
   chunks = std::max(chunks, p->col16.nchunks16);
   chunks = std::max(chunks, p->group.nchunks);
+  chunks = std::max(chunks, p->group_narrow.nchunks);
   return 2 * (size_t)(chunks > 0 ? chunks : 1) * (size_t)k;
 }
 
@@ -258,6 +259,10 @@ bool sliced_for(const gcn_spmm_plan* p, int k) {
 
 // rows of the slice-by-slice copy of B the group kernels gather from (decides their addressing mode, spmm_group.hip)
 long long group_table_rows(const gcn_spmm_plan* p) { return (long long)p->slicing.S * ((long long)p->group.w + 1); }
+// the slice set of the call in progress (plan.h: group_narrow for k <= 32 once it exists, else the plan's own)
+const gcn::GroupStream& cur_group(const gcn_spmm_plan* p) { return p->use_narrow ? p->group_narrow : p->group; }
+int cur_slices(const gcn_spmm_plan* p) { return p->use_narrow ? p->narrow_S : p->slicing.S; }
+long long cur_table_rows(const gcn_spmm_plan* p) { return (long long)cur_slices(p) * ((long long)cur_group(p).w + 1); }
 
 // would the sliced launch of a k-wide SpMM run a value-free kernel (and is the scaled copy of B worth it)?
 bool valless_pays(const gcn_spmm_plan* p, int k, int ldb) {
@@ -315,10 +320,10 @@ bool odd_width_detour(const gcn_spmm_plan* p, int k) {
 // rows [s*(w+1), (s+1)*(w+1)) with row w of every slice zero.
 int relay_B(gcn_spmm_plan* p, const float* B, int k, int ldb, bool scaled, bool group_layout, hipStream_t st) {
   if (group_layout) {                                  // (weighted pass: the same layout, rows not scaled)
-    const size_t rows = (size_t)p->slicing.S * (size_t)(p->group.w + 1);
+    const size_t rows = (size_t)cur_table_rows(p);
     const int rc = grow(p->bpad, rows * (size_t)ldb);
     if (rc != GCN_OK) return rc;
-    return gcn::launch_scale_rows_sliced(p->bpad, B, scaled ? p->factors.u_col : nullptr, p->n, k, ldb, p->slicing.S, p->group.w,
+    return gcn::launch_scale_rows_sliced(p->bpad, B, scaled ? p->factors.u_col : nullptr, p->n, k, ldb, cur_slices(p), cur_group(p).w,
                                          st) == hipSuccess ? GCN_OK : GCN_ERR_HIP;
   }
   const int rc = grow(p->bpad, ((size_t)p->n + 1) * (size_t)ldb);
@@ -424,16 +429,19 @@ int spmm_impl(gcn_spmm_plan* p, const int32_t* rowptr, const int32_t* col, const
   // sliced: the slice-major virtual CSR (S*m rows) into the partial buffer, then the per-row reduction
   // over slices, which carries the whole epilogue (bias, ReLU, dropout mask, row factor)
   const gcn::Slicing& sl = p->slicing;
-  if (grow(p->cv, (size_t)sl.S * (size_t)p->m * (size_t)k) != GCN_OK) return GCN_ERR_ALLOC;
+  const bool grp = group_launch(p, valless, weighted);
+  const int S_run = grp ? cur_slices(p) : sl.S;
+  if (grow(p->cv, (size_t)S_run * (size_t)p->m * (size_t)k) != GCN_OK) return GCN_ERR_ALLOC;
   *dropped = epi.drop.on();
-  if (group_launch(p, valless, weighted)) {
+  if (grp) {
     // four independent 16-lane row engines per wave on the 15-bit slice-major stream (spmm_group.hip)
+    const gcn::GroupStream& G = cur_group(p);
     gcn::GroupArgs ga;
-    ga.stream = p->group.stream; ga.chunk_meta = p->group.chunk_meta;
-    ga.vals = weighted ? p->group.vals.get() : nullptr;
+    ga.stream = G.stream; ga.chunk_meta = G.chunk_meta;
+    ga.vals = weighted ? G.vals.get() : nullptr;
     ga.Bp = a.B; ga.Cv = p->cv; ga.P = p->ws;
-    ga.nchunks = p->group.nchunks; ga.T = p->group.T; ga.k = k; ga.ldb = a.ldb;
-    ga.table_rows = group_table_rows(p);
+    ga.nchunks = G.nchunks; ga.T = G.T; ga.k = k; ga.ldb = a.ldb;
+    ga.table_rows = cur_table_rows(p);
     ga.store_policy = gcn::group_store();
     ga.ring = gcn::group_ring() ? 1 : 0;
     ga.merge_tiles = gcn::group_merge_tiles() ? 1 : 0;
@@ -444,9 +452,9 @@ int spmm_impl(gcn_spmm_plan* p, const int32_t* rowptr, const int32_t* col, const
     // rows cut by chunk ends: their later pieces are added by the reduction itself (cut lists per output row), or —
     // GCN_AMD_GROUP_FUSED_FIXUP=0, or a plan without the lists — by a pass of their own in front of it
     gcn::CutLists cuts;
-    if (gcn::group_fused_fixup() && p->group.cutptr) { cuts.ptr = p->group.cutptr; cuts.chunk = p->group.cutchunk; cuts.P = p->ws; }
-    else if (gcn::launch_group_fixup(p->group.fix, p->group.nfix, p->ws, p->cv, k, st) != hipSuccess) return GCN_ERR_HIP;
-    return gcn::launch_slice_reduce(p->cv, C, bias, relu, p->m, sl.S, k, st, 0, weighted ? nullptr : p->factors.u_row.get(),
+    if (gcn::group_fused_fixup() && G.cutptr) { cuts.ptr = G.cutptr; cuts.chunk = G.cutchunk; cuts.P = p->ws; }
+    else if (gcn::launch_group_fixup(G.fix, G.nfix, p->ws, p->cv, k, st) != hipSuccess) return GCN_ERR_HIP;
+    return gcn::launch_slice_reduce(p->cv, C, bias, relu, p->m, S_run, k, st, 0, weighted ? nullptr : p->factors.u_row.get(),
                                     epi.drop, nullptr, epi.outscale, epi.gap_w, cuts) == hipSuccess ? GCN_OK : GCN_ERR_HIP;
   }
   a.rowptr = sl.vrowptr; a.col = sl.vcol; a.val = sl.vval; a.chunk_row = sl.vchunk_row;
@@ -498,6 +506,7 @@ void build_sliced_streams(gcn_spmm_plan* p, hipStream_t st) {
       return;
     }
     p->group = gcn::GroupStream{};
+  p->group_narrow = gcn::GroupStream{}; p->narrow_S = 0; p->narrow_tried = false; p->use_narrow = false;
   }
   if (!p->factors.ready()) return;
   // 16-bit column stream of the four-per-gather kernel (2 instead of 4 index bytes per non-zero): slices at
@@ -578,6 +587,57 @@ size_t gcn_spmm_plan_workspace_bytes(const gcn_spmm_plan_t* p, int32_t k) {
   return (!p || k <= 0) ? 0 : sizeof(float) * ws_elems(p, k);
 }
 
+namespace {
+
+// The second slice set of a plan (plan.h, group_narrow): for k <= 32 a row of the table is 128 bytes, so an L2 holds a
+// slice twice as wide and the matrix needs about half the slices — and every slice costs a partial row per matrix row.
+// Reddit-shaped (profiles/r03ad_narrow_widths_slice_counts.log): k = 16 / 32 whole SpMM 0.696 / 0.806 ms on the plan's 15
+// slices, 0.668 / 0.762 on 10.  Built once, at the first narrow call of a value-free plan with an automatic slice count,
+// from the CSR the call hands over (a transient virtual CSR; only the stream, its chunk table and cut lists are kept:
+// 2 bytes per non-zero).  Anything that fails leaves the plan on its own slices.  GCN_AMD_GROUP_NARROW_SLICES=0: off.
+void maybe_build_narrow(gcn_spmm_plan* p, const int32_t* rowptr, const int32_t* col, const float* val, hipStream_t st) {
+  if (p->narrow_tried) return;
+  p->narrow_tried = true;
+  static const bool on = gcn::env_on("GCN_AMD_GROUP_NARROW_SLICES");
+  if (!on || !p->slices_auto || !p->group.ready() || p->group.vals || !value_free_plan(p) || p->nnz <= 0) return;
+  const long long l2 = 4LL << 20;
+  long long S2 = ((long long)p->n * 128 + l2 - 1) / l2;
+  const long long by_entry = ((long long)p->n + 32766) / 32767;       // 15-bit entries: slices <= 32 767 columns
+  if (S2 < by_entry) S2 = by_entry;
+  if (S2 > (long long)p->nnz / p->m / 16) S2 = (long long)p->nnz / p->m / 16;
+  if (S2 < 2 || S2 + 2 > p->slicing.S) return;                        // (not enough fewer to pay for a second stream)
+  const int S = (int)S2, w = (p->n + S - 1) / S;
+  if (w > 32767) return;
+  const long long vm = (long long)S * p->m;
+  gcn::DevBuf<int> vrowptr, vcol, vrowptr_g;
+  gcn::DevBuf<float> vval;
+  if (vrowptr.alloc((size_t)vm + 1) != hipSuccess || vcol.alloc((size_t)p->nnz) != hipSuccess ||
+      vval.alloc((size_t)p->nnz) != hipSuccess || vrowptr_g.alloc((size_t)vm + 1) != hipSuccess) return;
+  int sorted = 0;
+  if (gcn::build_sliced_csr(rowptr, col, val, p->m, p->n, p->nnz, S, vrowptr, vcol, vval, &sorted, st) != hipSuccess || !sorted) return;
+  unsigned short* stream = nullptr;
+  int *chunk_row = nullptr, *chunk_meta = nullptr, *fix = nullptr, *cutptr = nullptr, *cutchunk = nullptr, nch = 0, nfix = 0, ncut = 0;
+  const int gT = gcn::group_chunk(p->nnz, p->cu_count);
+  if (gcn::build_group_stream(vrowptr, vcol, p->m, p->n, S, gT, vrowptr_g, &stream, &chunk_row, &chunk_meta, &nch, &fix, &nfix, st,
+                              nullptr, nullptr, &cutptr, &cutchunk, &ncut) != hipSuccess || nch <= 0) return;
+  gcn::GroupStream& g = p->group_narrow;
+  g.fix.adopt(fix, 4 * (size_t)nfix); g.nfix = nfix;
+  g.cutptr.adopt(cutptr, (size_t)p->m + 1); g.cutchunk.adopt(cutchunk, (size_t)(ncut > 0 ? ncut : 1)); g.ncut = ncut;
+  g.stream.adopt(stream, (size_t)nch * (size_t)gT);
+  g.chunk_meta.adopt(chunk_meta, 2 * (size_t)nch);
+  g.chunk_row.adopt(chunk_row, (size_t)nch); g.chunk_row.reset();
+  g.nchunks = nch; g.T = gT; g.w = w;
+  p->narrow_S = S;
+  if (gcn::verbose()) std::fprintf(stderr, "libgcnspmm: second slice set for k <= 32: %d slices of %d columns (the plan's own: %d)\n", S, w, p->slicing.S);
+}
+
+// does a k-wide call (k already rounded up to a multiple of 4) of this plan run on the second slice set?
+bool narrow_set_for(const gcn_spmm_plan* p, int k, int ldb) {
+  return k <= 32 && p->group_narrow.ready() && valless_pays(p, k, ldb) && group_launch(p, true, false);
+}
+
+}  // namespace
+
 int gcn_spmm_csr_f32_epilogue(gcn_spmm_plan_t* p, const int32_t* rowptr, const int32_t* col, const float* val,
                               const float* B, float* C, const float* bias, int32_t relu, float dropout_p,
                               uint64_t seed, uint64_t offset, int32_t k, void* stream) {
@@ -585,6 +645,15 @@ int gcn_spmm_csr_f32_epilogue(gcn_spmm_plan_t* p, const int32_t* rowptr, const i
   if (p->m == 0 || k == 0) return GCN_OK;
   if (!C || !rowptr || (p->nnz > 0 && (!col || !val || !B))) return GCN_ERR_INVALID_ARG;
   hipStream_t st = (hipStream_t)stream;
+  {                                                    // which slice set does this call run on?
+    const bool odd = odd_width_detour(p, k);
+    const int kq = odd ? (k + 3) / 4 * 4 : k, ldq = odd ? (kq + 31) / 32 * 32 : gcn::padded_ldb(p->n, k);
+    p->use_narrow = false;
+    if (kq <= 32 && p->nnz > 0 && valless_pays(p, kq, ldq) && group_launch(p, true, false)) {
+      maybe_build_narrow(p, rowptr, col, val, st);
+      p->use_narrow = narrow_set_for(p, kq, ldq);
+    }
+  }
   Epilogue epi;
   epi.bias = bias; epi.relu = relu ? 1 : 0;
   epi.drop.p = dropout_p; epi.drop.seed = seed; epi.drop.offset = offset;
@@ -650,6 +719,7 @@ int gcn_spmm_csr_f32_prelaid(gcn_spmm_plan_t* p, const int32_t* rowptr, const in
   epi.outscale = out_scale;
   epi.gap_w = out_gap;
   bool dropped = false;
+  p->use_narrow = false;                               // (the pre-laid layout is the plan's own slice set, whatever the width)
   return spmm_impl(p, rowptr, col, val, Bp, ld, /*b_scaled=*/true, out, epi, k, (hipStream_t)stream, &dropped);
 }
 
@@ -674,6 +744,7 @@ int gcn_spmm_plan_enable_slicing(gcn_spmm_plan_t* p, const int32_t* rowptr, cons
   p->slicing = gcn::Slicing{};
   p->col16 = gcn::Col16Stream{};
   p->group = gcn::GroupStream{};
+  p->group_narrow = gcn::GroupStream{}; p->narrow_S = 0; p->narrow_tried = false; p->use_narrow = false;
   p->cv.reset();
   const bool autom = slices == -1;
   p->slices_auto = autom;
@@ -730,6 +801,7 @@ int gcn_spmm_plan_enable_slicing(gcn_spmm_plan_t* p, const int32_t* rowptr, cons
 }
 
 int32_t gcn_spmm_plan_num_slices(const gcn_spmm_plan_t* p) { return p ? p->slicing.S : -1; }
+int32_t gcn_spmm_plan_narrow_slices(const gcn_spmm_plan_t* p) { return p ? (p->group_narrow.ready() ? p->narrow_S : 0) : -1; }
 
 int gcn_spmm_plan_set_value_factors(gcn_spmm_plan_t* p, const int32_t* rowptr, const int32_t* col,
                                     const float* val, const float* u_row, const float* u_col, void* stream) {
@@ -737,6 +809,7 @@ int gcn_spmm_plan_set_value_factors(gcn_spmm_plan_t* p, const int32_t* rowptr, c
   p->factors = gcn::Factors{};
   p->col16 = gcn::Col16Stream{};                       // (the value-free streams exist only beside factors)
   p->group = gcn::GroupStream{};
+  p->group_narrow = gcn::GroupStream{}; p->narrow_S = 0; p->narrow_tried = false; p->use_narrow = false;
   if (!u_row && !u_col) {                                           // (null, null): forget the factors;
     build_sliced_streams(p, (hipStream_t)stream);                   // the sliced plan goes back to its value stream
     return GCN_OK;
@@ -922,7 +995,8 @@ int gcn_spmm_plan_main_kernel(const gcn_spmm_plan_t* p, int32_t k, int32_t epilo
   if (a.valless && group_pass(p)) {
     gcn::GroupArgs probe{};
     probe.k = a.k; probe.ldb = ld_eff; probe.table_rows = group_table_rows(p); probe.ring = gcn::group_ring() ? 1 : 0;
-    if (gcn::group8_enabled() && a.k <= 32 && p->group.nchunks % 64 == 0)
+    const int nch8 = (a.k <= 32 && p->group_narrow.ready()) ? p->group_narrow.nchunks : p->group.nchunks;
+    if (gcn::group8_enabled() && a.k <= 32 && nch8 % 64 == 0)
       snprintf(buf, (size_t)buflen, "gcn::spmm_group8_kernel<%s, %s>", gcn::group_ring() ? "true" : "false", bigs);
     else if (gcn::spmm_group12_applies(probe))
       snprintf(buf, (size_t)buflen, "gcn::spmm_group12_kernel");

@@ -158,6 +158,13 @@ struct gcn_spmm_plan {
   bool slices_auto = false;                         // the slice count was chosen by auto_slices (enable_slicing(-1))
   gcn::Col16Stream col16;
   gcn::GroupStream group;
+  // k <= 32 (value-free plans whose slice count was automatic): the same matrix cut into FEWER, wider slices — a row of
+  // the table is 128 bytes there, so half as many slices fill an L2, and the partial rows (whose cost goes with the
+  // slice count) halve.  Built at the first narrow call (api_spmm.cpp, maybe_build_narrow); `use_narrow`: the set the
+  // call in progress runs on.
+  gcn::GroupStream group_narrow;
+  int narrow_S = 0;
+  bool narrow_tried = false, use_narrow = false;
   gcn::Factors factors;
   gcn::Panels panels;
 };

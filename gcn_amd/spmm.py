@@ -170,6 +170,11 @@ class CsrAdjacency:
     def num_slices(self):
         return int(_lib.load().gcn_spmm_plan_num_slices(self.plan))
 
+    @property
+    def narrow_slices(self):
+        """slices of the second slice set (k <= 32; built at the first such call of a value-free, auto-sliced plan), 0: none"""
+        return int(_lib.load().gcn_spmm_plan_narrow_slices(self.plan))
+
     def num_passes(self, k):
         """main-kernel launches (column passes) one k-wide SpMM issues"""
         return int(_lib.load().gcn_spmm_plan_num_passes(self.plan, int(k)))

@@ -1107,3 +1107,40 @@ def test_spmm_can_be_captured_in_a_hip_graph_and_replayed(shape):
         if bias is not None:
             ref = np.maximum(ref + bias, 0)
         assert rel_err(out.cpu().numpy(), ref) <= TOL, (shape, name)
+
+
+@pytest.mark.parametrize("scale", [0.5, 1.0])
+def test_second_slice_set_for_narrow_widths(scale):
+    """a value-free plan with an automatic slice count cuts the matrix a SECOND time, into about half as many slices, at
+    its first call with k <= 32 (a table row is 128 bytes there): Reddit-shaped at half / full size: 8 -> 4 / 15 -> 8
+    slices.  Wide calls stay on the plan's own slices, narrow ones (incl. odd widths and the epilogue) run on the second
+    set; every result against the fp64 oracle on sampled rows, bitwise repeatable; an explicit slice count builds none."""
+    from util import sampled_rows_oracle_err
+    d = _dev()
+    rowptr, col, val, n = graphgen.make_graph("reddit", device=d, seed=1, scale=scale)
+    adj = gcn_amd.CsrAdjacency(rowptr, col, val, (n, n), symmetric=True)
+    S = adj.num_slices
+    assert S == (15 if scale == 1.0 else 8) and adj.has_value_factors and adj.narrow_slices == 0
+    rows = np.random.default_rng(3).choice(n, 1024, replace=False); rows.sort()
+    B128 = graphgen.random_features(n, 128, seed=2, device=d)
+    C128 = adj.matmul_raw(B128)
+    assert adj.narrow_slices == 0                                            # (no narrow call so far)
+    expect = 8 if scale == 1.0 else 4
+    for k in (16, 32, 12, 30, 7):
+        B = graphgen.random_features(n, k, seed=10 + k, device=d)
+        C = adj.matmul_raw(B)
+        if k >= 12:
+            assert adj.narrow_slices == expect, (k, adj.narrow_slices)
+            assert adj.main_kernel(k).startswith("gcn::spmm_group8_kernel<"), adj.main_kernel(k)
+        assert sampled_rows_oracle_err(rowptr, col, val, B, C, rows)[0] <= TOL, k
+        assert torch.equal(C, adj.matmul_raw(B))
+    bias = torch.randn(16, device=d)
+    B = graphgen.random_features(n, 16, seed=77, device=d)
+    Ce = adj.matmul_raw(B, bias=bias, relu=True)
+    assert float((Ce - torch.relu(adj.matmul_raw(B) + bias)).abs().max()) <= 1e-5 * float(Ce.abs().max())
+    assert torch.equal(C128, adj.matmul_raw(B128)) and adj.num_slices == S    # the wide path did not move
+    assert sampled_rows_oracle_err(rowptr, col, val, B128, C128, rows)[0] <= TOL
+    if scale == 0.5:
+        fixed = gcn_amd.CsrAdjacency(rowptr, col, val, (n, n), symmetric=True, slices=8)
+        fixed.matmul_raw(graphgen.random_features(n, 16, seed=5, device=d))
+        assert fixed.num_slices == 8 and fixed.narrow_slices == 0
