@@ -231,7 +231,7 @@ size_t ws_elems(const gcn_spmm_plan* p, int k) {
   int chunks = std::max(p->nchunks, p->panels.out_nchunks);
   chunks = std::max(chunks, p->col16.nchunks16);
   chunks = std::max(chunks, p->group.nchunks);
-  chunks = std::max(chunks, p->group_narrow.nchunks);
+  chunks = std::max(chunks, std::max(p->group_alt[0].nchunks, p->group_alt[1].nchunks));
   return 2 * (size_t)(chunks > 0 ? chunks : 1) * (size_t)k;
 }
 
@@ -259,9 +259,9 @@ bool sliced_for(const gcn_spmm_plan* p, int k) {
 
 // rows of the slice-by-slice copy of B the group kernels gather from (decides their addressing mode, spmm_group.hip)
 long long group_table_rows(const gcn_spmm_plan* p) { return (long long)p->slicing.S * ((long long)p->group.w + 1); }
-// the slice set of the call in progress (plan.h: group_narrow for k <= 32 once it exists, else the plan's own)
-const gcn::GroupStream& cur_group(const gcn_spmm_plan* p) { return p->use_narrow ? p->group_narrow : p->group; }
-int cur_slices(const gcn_spmm_plan* p) { return p->use_narrow ? p->narrow_S : p->slicing.S; }
+// the slice set of the call in progress (plan.h: group_alt for the narrow width classes once they exist, else the plan's own)
+const gcn::GroupStream& cur_group(const gcn_spmm_plan* p) { return p->use_alt >= 0 ? p->group_alt[p->use_alt] : p->group; }
+int cur_slices(const gcn_spmm_plan* p) { return p->use_alt >= 0 ? p->alt_S[p->use_alt] : p->slicing.S; }
 long long cur_table_rows(const gcn_spmm_plan* p) { return (long long)cur_slices(p) * ((long long)cur_group(p).w + 1); }
 
 // would the sliced launch of a k-wide SpMM run a value-free kernel (and is the scaled copy of B worth it)?
@@ -506,7 +506,8 @@ void build_sliced_streams(gcn_spmm_plan* p, hipStream_t st) {
       return;
     }
     p->group = gcn::GroupStream{};
-  p->group_narrow = gcn::GroupStream{}; p->narrow_S = 0; p->narrow_tried = false; p->use_narrow = false;
+  for (int c_ = 0; c_ < 2; ++c_) { p->group_alt[c_] = gcn::GroupStream{}; p->alt_S[c_] = 0; p->alt_tried[c_] = false; }
+  p->use_alt = -1;
   }
   if (!p->factors.ready()) return;
   // 16-bit column stream of the four-per-gather kernel (2 instead of 4 index bytes per non-zero): slices at
@@ -589,23 +590,26 @@ size_t gcn_spmm_plan_workspace_bytes(const gcn_spmm_plan_t* p, int32_t k) {
 
 namespace {
 
-// The second slice set of a plan (plan.h, group_narrow): for k <= 32 a row of the table is 128 bytes, so an L2 holds a
+// The narrow slice set of a plan (plan.h, group_alt[0]): for k <= 32 a row of the table is 128 bytes, so an L2 holds a
 // slice twice as wide and the matrix needs about half the slices — and every slice costs a partial row per matrix row.
-// Reddit-shaped (profiles/r03ad_narrow_widths_slice_counts.log): k = 16 / 32 whole SpMM 0.696 / 0.806 ms on the plan's 15
-// slices, 0.668 / 0.762 on 10.  Built once, at the first narrow call of a value-free plan with an automatic slice count,
-// from the CSR the call hands over (a transient virtual CSR; only the stream, its chunk table and cut lists are kept:
-// 2 bytes per non-zero).  Anything that fails leaves the plan on its own slices.  GCN_AMD_GROUP_NARROW_SLICES=0: off.
-void maybe_build_narrow(gcn_spmm_plan* p, const int32_t* rowptr, const int32_t* col, const float* val, hipStream_t st) {
-  if (p->narrow_tried) return;
-  p->narrow_tried = true;
+// Reddit-shaped (profiles/r03az_*): 8 slices instead of 15; k = 16 / 32 whole SpMM 0.684 / 0.782 -> 0.655 / 0.746 ms.
+// Built once, at the first such call of a value-free plan with an automatic slice count, from the CSR the call hands
+// over (a transient virtual CSR;
+// only the stream, its chunk table and cut lists are kept: 2 bytes per non-zero).  Anything that fails leaves the plan
+// on its own slices.  GCN_AMD_GROUP_NARROW_SLICES=0: off.
+int alt_class(int k) { return k <= 32 ? 0 : -1; }
+
+void maybe_build_alt(gcn_spmm_plan* p, int cls, const int32_t* rowptr, const int32_t* col, const float* val, hipStream_t st) {
+  if (cls < 0 || p->alt_tried[cls]) return;
+  p->alt_tried[cls] = true;
   static const bool on = gcn::env_on("GCN_AMD_GROUP_NARROW_SLICES");
   if (!on || !p->slices_auto || !p->group.ready() || p->group.vals || !value_free_plan(p) || p->nnz <= 0) return;
-  const long long l2 = 4LL << 20;
-  long long S2 = ((long long)p->n * 128 + l2 - 1) / l2;
+  const long long l2 = 4LL << 20, row_bytes = 128;
+  long long S2 = ((long long)p->n * row_bytes + l2 - 1) / l2;
   const long long by_entry = ((long long)p->n + 32766) / 32767;       // 15-bit entries: slices <= 32 767 columns
   if (S2 < by_entry) S2 = by_entry;
   if (S2 > (long long)p->nnz / p->m / 16) S2 = (long long)p->nnz / p->m / 16;
-  if (S2 < 2 || S2 + 2 > p->slicing.S) return;                        // (not enough fewer to pay for a second stream)
+  if (S2 < 2 || S2 + 2 > p->slicing.S) return;                        // (not enough fewer to pay for another stream)
   const int S = (int)S2, w = (p->n + S - 1) / S;
   if (w > 32767) return;
   const long long vm = (long long)S * p->m;
@@ -620,20 +624,38 @@ void maybe_build_narrow(gcn_spmm_plan* p, const int32_t* rowptr, const int32_t* 
   const int gT = gcn::group_chunk(p->nnz, p->cu_count);
   if (gcn::build_group_stream(vrowptr, vcol, p->m, p->n, S, gT, vrowptr_g, &stream, &chunk_row, &chunk_meta, &nch, &fix, &nfix, st,
                               nullptr, nullptr, &cutptr, &cutchunk, &ncut) != hipSuccess || nch <= 0) return;
-  gcn::GroupStream& g = p->group_narrow;
+  gcn::GroupStream& g = p->group_alt[cls];
   g.fix.adopt(fix, 4 * (size_t)nfix); g.nfix = nfix;
   g.cutptr.adopt(cutptr, (size_t)p->m + 1); g.cutchunk.adopt(cutchunk, (size_t)(ncut > 0 ? ncut : 1)); g.ncut = ncut;
   g.stream.adopt(stream, (size_t)nch * (size_t)gT);
   g.chunk_meta.adopt(chunk_meta, 2 * (size_t)nch);
   g.chunk_row.adopt(chunk_row, (size_t)nch); g.chunk_row.reset();
   g.nchunks = nch; g.T = gT; g.w = w;
-  p->narrow_S = S;
-  if (gcn::verbose()) std::fprintf(stderr, "libgcnspmm: second slice set for k <= 32: %d slices of %d columns (the plan's own: %d)\n", S, w, p->slicing.S);
+  p->alt_S[cls] = S;
+  if (gcn::verbose())
+    std::fprintf(stderr, "libgcnspmm: slice set for k <= 32: %d slices of %d columns (the plan's own: %d)\n", S, w, p->slicing.S);
 }
 
-// does a k-wide call (k already rounded up to a multiple of 4) of this plan run on the second slice set?
-bool narrow_set_for(const gcn_spmm_plan* p, int k, int ldb) {
-  return k <= 32 && p->group_narrow.ready() && valless_pays(p, k, ldb) && group_launch(p, true, false);
+// Which slice set does a k-wide call run on (k already rounded up to a multiple of 4; *ldb the row stride it would
+// gather with)?  Builds the narrow set on first use.  Widths 33..48 on the five-engine kernel stay on the plan's own
+// slices; where the row stride would have been padded to 64 floats (k = 44 and the odd widths' k' detour) they gather
+// from rows of 48 instead (192 bytes: always two lines, a quarter less table and copy): *ldb = 48, *relay = the call
+// lays that copy out itself (k = 41 / 47: 1.39 / 1.36 -> 1.34 / 1.30 ms; 36 / 40 keep their dense rows).  (A slice set of their own — 11..13 slices
+// instead of 15 — was built and measured: +-1 %, profiles/r03ba_*; not kept.)
+int pick_slice_set(gcn_spmm_plan* p, int k, int* ldb, bool* relay, const int32_t* rowptr, const int32_t* col, const float* val,
+                   hipStream_t st) {
+  *relay = false;
+  if (p->nnz <= 0 || k % 4 != 0) return -1;
+  if (k > 32 && k <= 48 && *ldb > 48 && valless_pays(p, k, 48) && group_launch(p, true, false)) {
+    gcn::GroupArgs probe{};
+    probe.k = k; probe.ldb = 48; probe.table_rows = group_table_rows(p); probe.ring = gcn::group_ring() ? 1 : 0;
+    if (gcn::spmm_group12_applies(probe)) { *ldb = 48; *relay = true; }
+    return -1;
+  }
+  const int cls = alt_class(k);
+  if (cls < 0 || !valless_pays(p, k, *ldb) || !group_launch(p, true, false)) return -1;
+  maybe_build_alt(p, cls, rowptr, col, val, st);
+  return p->group_alt[cls].ready() ? cls : -1;
 }
 
 }  // namespace
@@ -645,15 +667,11 @@ int gcn_spmm_csr_f32_epilogue(gcn_spmm_plan_t* p, const int32_t* rowptr, const i
   if (p->m == 0 || k == 0) return GCN_OK;
   if (!C || !rowptr || (p->nnz > 0 && (!col || !val || !B))) return GCN_ERR_INVALID_ARG;
   hipStream_t st = (hipStream_t)stream;
-  {                                                    // which slice set does this call run on?
-    const bool odd = odd_width_detour(p, k);
-    const int kq = odd ? (k + 3) / 4 * 4 : k, ldq = odd ? (kq + 31) / 32 * 32 : gcn::padded_ldb(p->n, k);
-    p->use_narrow = false;
-    if (kq <= 32 && p->nnz > 0 && valless_pays(p, kq, ldq) && group_launch(p, true, false)) {
-      maybe_build_narrow(p, rowptr, col, val, st);
-      p->use_narrow = narrow_set_for(p, kq, ldq);
-    }
-  }
+  // which slice set does this call run on?  (decided here, once, for the re-laid copy of B and the kernels alike)
+  const bool odd = odd_width_detour(p, k);
+  int ld_call = odd ? ((k + 3) / 4 * 4 + 31) / 32 * 32 : gcn::padded_ldb(p->n, k);
+  bool relay48 = false;
+  p->use_alt = pick_slice_set(p, odd ? (k + 3) / 4 * 4 : k, &ld_call, &relay48, rowptr, col, val, st);
   Epilogue epi;
   epi.bias = bias; epi.relu = relu ? 1 : 0;
   epi.drop.p = dropout_p; epi.drop.seed = seed; epi.drop.offset = offset;
@@ -664,8 +682,8 @@ int gcn_spmm_csr_f32_epilogue(gcn_spmm_plan_t* p, const int32_t* rowptr, const i
   // B re-laid with zero columns (stride a multiple of 32 floats), the product into a k'-wide scratch
   // result, and one pass that compacts it into C (and applies bias / ReLU).  Reddit-shaped k = 41:
   // 2.13 -> 1.87 ms.  Same limits as the B padding (tables <= 768 MiB), panels excluded.
-  if (odd_width_detour(p, k)) {
-    const int kp = (k + 3) / 4 * 4, ldb = (kp + 31) / 32 * 32;
+  if (odd) {
+    const int kp = (k + 3) / 4 * 4, ldb = ld_call;
     if (grow(p->cpad, (size_t)p->m * (size_t)kp) != GCN_OK) return GCN_ERR_ALLOC;
     const bool scaled = valless_pays(p, kp, ldb);      // the copy can carry the u_col scaling
     const bool weighted = !scaled && weighted_pass(p, kp, ldb);
@@ -673,6 +691,9 @@ int gcn_spmm_csr_f32_epilogue(gcn_spmm_plan_t* p, const int32_t* rowptr, const i
     if ((rc = spmm_impl(p, rowptr, col, val, p->bpad, ldb, scaled, p->cpad, Epilogue{}, kp, st, &dropped)) != GCN_OK) return rc;
     if (gcn::launch_unpad_rows(C, p->cpad, bias, epi.relu, p->m, k, kp, st) != hipSuccess) return GCN_ERR_HIP;
     dropped = false;
+  } else if (relay48) {                                // k = 44 on the five-engine kernel: rows of 48 floats, scaled, slice by slice
+    if ((rc = relay_B(p, B, k, ld_call, true, true, st)) != GCN_OK) return rc;
+    if ((rc = spmm_impl(p, rowptr, col, val, p->bpad, ld_call, true, C, epi, k, st, &dropped)) != GCN_OK) return rc;
   } else {
     if ((rc = spmm_impl(p, rowptr, col, val, B, 0, false, C, epi, k, st, &dropped)) != GCN_OK) return rc;
   }
@@ -719,7 +740,7 @@ int gcn_spmm_csr_f32_prelaid(gcn_spmm_plan_t* p, const int32_t* rowptr, const in
   epi.outscale = out_scale;
   epi.gap_w = out_gap;
   bool dropped = false;
-  p->use_narrow = false;                               // (the pre-laid layout is the plan's own slice set, whatever the width)
+  p->use_alt = -1;                                     // (the pre-laid layout is the plan's own slice set, whatever the width)
   return spmm_impl(p, rowptr, col, val, Bp, ld, /*b_scaled=*/true, out, epi, k, (hipStream_t)stream, &dropped);
 }
 
@@ -744,7 +765,8 @@ int gcn_spmm_plan_enable_slicing(gcn_spmm_plan_t* p, const int32_t* rowptr, cons
   p->slicing = gcn::Slicing{};
   p->col16 = gcn::Col16Stream{};
   p->group = gcn::GroupStream{};
-  p->group_narrow = gcn::GroupStream{}; p->narrow_S = 0; p->narrow_tried = false; p->use_narrow = false;
+  for (int c_ = 0; c_ < 2; ++c_) { p->group_alt[c_] = gcn::GroupStream{}; p->alt_S[c_] = 0; p->alt_tried[c_] = false; }
+  p->use_alt = -1;
   p->cv.reset();
   const bool autom = slices == -1;
   p->slices_auto = autom;
@@ -801,7 +823,11 @@ int gcn_spmm_plan_enable_slicing(gcn_spmm_plan_t* p, const int32_t* rowptr, cons
 }
 
 int32_t gcn_spmm_plan_num_slices(const gcn_spmm_plan_t* p) { return p ? p->slicing.S : -1; }
-int32_t gcn_spmm_plan_narrow_slices(const gcn_spmm_plan_t* p) { return p ? (p->group_narrow.ready() ? p->narrow_S : 0) : -1; }
+int32_t gcn_spmm_plan_narrow_slices(const gcn_spmm_plan_t* p, int32_t k) {
+  if (!p || k <= 0) return -1;
+  const int cls = alt_class((k + 3) / 4 * 4);
+  return cls >= 0 && p->group_alt[cls].ready() ? p->alt_S[cls] : 0;
+}
 
 int gcn_spmm_plan_set_value_factors(gcn_spmm_plan_t* p, const int32_t* rowptr, const int32_t* col,
                                     const float* val, const float* u_row, const float* u_col, void* stream) {
@@ -809,7 +835,8 @@ int gcn_spmm_plan_set_value_factors(gcn_spmm_plan_t* p, const int32_t* rowptr, c
   p->factors = gcn::Factors{};
   p->col16 = gcn::Col16Stream{};                       // (the value-free streams exist only beside factors)
   p->group = gcn::GroupStream{};
-  p->group_narrow = gcn::GroupStream{}; p->narrow_S = 0; p->narrow_tried = false; p->use_narrow = false;
+  for (int c_ = 0; c_ < 2; ++c_) { p->group_alt[c_] = gcn::GroupStream{}; p->alt_S[c_] = 0; p->alt_tried[c_] = false; }
+  p->use_alt = -1;
   if (!u_row && !u_col) {                                           // (null, null): forget the factors;
     build_sliced_streams(p, (hipStream_t)stream);                   // the sliced plan goes back to its value stream
     return GCN_OK;
@@ -995,7 +1022,7 @@ int gcn_spmm_plan_main_kernel(const gcn_spmm_plan_t* p, int32_t k, int32_t epilo
   if (a.valless && group_pass(p)) {
     gcn::GroupArgs probe{};
     probe.k = a.k; probe.ldb = ld_eff; probe.table_rows = group_table_rows(p); probe.ring = gcn::group_ring() ? 1 : 0;
-    const int nch8 = (a.k <= 32 && p->group_narrow.ready()) ? p->group_narrow.nchunks : p->group.nchunks;
+    const int nch8 = (a.k <= 32 && p->group_alt[0].ready()) ? p->group_alt[0].nchunks : p->group.nchunks;
     if (gcn::group8_enabled() && a.k <= 32 && nch8 % 64 == 0)
       snprintf(buf, (size_t)buflen, "gcn::spmm_group8_kernel<%s, %s>", gcn::group_ring() ? "true" : "false", bigs);
     else if (gcn::spmm_group12_applies(probe))

@@ -158,13 +158,14 @@ struct gcn_spmm_plan {
   bool slices_auto = false;                         // the slice count was chosen by auto_slices (enable_slicing(-1))
   gcn::Col16Stream col16;
   gcn::GroupStream group;
-  // k <= 32 (value-free plans whose slice count was automatic): the same matrix cut into FEWER, wider slices — a row of
-  // the table is 128 bytes there, so half as many slices fill an L2, and the partial rows (whose cost goes with the
-  // slice count) halve.  Built at the first narrow call (api_spmm.cpp, maybe_build_narrow); `use_narrow`: the set the
-  // call in progress runs on.
-  gcn::GroupStream group_narrow;
-  int narrow_S = 0;
-  bool narrow_tried = false, use_narrow = false;
+  // Narrow widths (value-free plans whose slice count was automatic): the same matrix cut into FEWER, wider slices —
+  // class 0: k <= 32, a row of the table is 128 bytes, so half as many slices fill an L2 and the partial rows (whose cost
+  // goes with the slice count) halve.  (Class 1, 33..48 on 192-byte rows, was measured and is not built.)  Built at the
+  // first call of the class (api_spmm.cpp, maybe_build_alt); `use_alt`: the set the call in progress runs on (-1: the plan's own).
+  gcn::GroupStream group_alt[2];
+  int alt_S[2] = {0, 0};
+  bool alt_tried[2] = {false, false};
+  int use_alt = -1;
   gcn::Factors factors;
   gcn::Panels panels;
 };

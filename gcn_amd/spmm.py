@@ -170,10 +170,14 @@ class CsrAdjacency:
     def num_slices(self):
         return int(_lib.load().gcn_spmm_plan_num_slices(self.plan))
 
+    def narrow_slices_for(self, k):
+        """slices of the slice set a k-wide call runs on when that is not the plan's own (k <= 32, 33..48: built at the first
+        such call of a value-free, auto-sliced plan); 0: the plan's own"""
+        return int(_lib.load().gcn_spmm_plan_narrow_slices(self.plan, int(k)))
+
     @property
     def narrow_slices(self):
-        """slices of the second slice set (k <= 32; built at the first such call of a value-free, auto-sliced plan), 0: none"""
-        return int(_lib.load().gcn_spmm_plan_narrow_slices(self.plan))
+        return self.narrow_slices_for(16)
 
     def num_passes(self, k):
         """main-kernel launches (column passes) one k-wide SpMM issues"""

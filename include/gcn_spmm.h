@@ -153,10 +153,11 @@ int gcn_spmm_plan_enable_slicing(gcn_spmm_plan_t* plan, const int32_t* rowptr_de
                                  const int32_t* col_dev, const float* val_dev,
                                  int32_t slices, void* stream);
 int32_t gcn_spmm_plan_num_slices(const gcn_spmm_plan_t* plan);
-/* Slices of the plan's SECOND slice set, 0 while there is none.  Value-free plans whose slice count was automatic
- * build it at their first call with k <= 32: a table row is 128 bytes there, half as many slices fill an L2, and the
- * partial rows — whose cost goes with the slice count — halve (Reddit-shaped: 8 instead of 15). */
-int32_t gcn_spmm_plan_narrow_slices(const gcn_spmm_plan_t* plan);
+/* Slices of the slice set a k-wide call runs on when it is NOT the plan's own (0: it is).  Value-free plans whose slice
+ * count was automatic cut the matrix again at their first call with k <= 32: a table row is 128 bytes there, half as
+ * many slices fill an L2, and the partial rows — whose cost goes with the slice count — halve (Reddit-shaped: 8
+ * instead of 15). */
+int32_t gcn_spmm_plan_narrow_slices(const gcn_spmm_plan_t* plan, int32_t k);
 
 /* Rank-1 values.  When every stored value is u_row[r] * u_col[c] — the GCN normalisation
  * D^-1/2 (A+I) D^-1/2 has u = D^-1/2 — the sliced main pass runs WITHOUT its value stream (5 % of the

@@ -1111,9 +1111,9 @@ def test_spmm_can_be_captured_in_a_hip_graph_and_replayed(shape):
 
 @pytest.mark.parametrize("scale", [0.5, 1.0])
 def test_second_slice_set_for_narrow_widths(scale):
-    """a value-free plan with an automatic slice count cuts the matrix a SECOND time, into about half as many slices, at
-    its first call with k <= 32 (a table row is 128 bytes there): Reddit-shaped at half / full size: 8 -> 4 / 15 -> 8
-    slices.  Wide calls stay on the plan's own slices, narrow ones (incl. odd widths and the epilogue) run on the second
+    """a value-free plan with an automatic slice count cuts the matrix again, into fewer slices, at its first call of a
+    narrow width — k <= 32 (a table row is 128 bytes): Reddit-shaped at half / full size 8 -> 4 / 15 -> 8 slices;
+    33 <= k <= 48 stay on the plan's own slices (rows of 48 floats for the five-engine kernel).  Wide calls stay on the plan's own slices, narrow ones (incl. odd widths and the epilogue) run on the second
     set; every result against the fp64 oracle on sampled rows, bitwise repeatable; an explicit slice count builds none."""
     from util import sampled_rows_oracle_err
     d = _dev()
@@ -1134,6 +1134,13 @@ def test_second_slice_set_for_narrow_widths(scale):
             assert adj.main_kernel(k).startswith("gcn::spmm_group8_kernel<"), adj.main_kernel(k)
         assert sampled_rows_oracle_err(rowptr, col, val, B, C, rows)[0] <= TOL, k
         assert torch.equal(C, adj.matmul_raw(B))
+    for k in (44, 48, 36, 41, 47):                                           # 33..48: the plan's own slices, rows of 48 floats
+        B = graphgen.random_features(n, k, seed=10 + k, device=d)
+        C = adj.matmul_raw(B)
+        assert adj.narrow_slices_for(k) == 0 and adj.main_kernel(k) == "gcn::spmm_group12_kernel", (k, adj.narrow_slices_for(k))
+        assert sampled_rows_oracle_err(rowptr, col, val, B, C, rows)[0] <= TOL, k
+        assert torch.equal(C, adj.matmul_raw(B))
+    assert adj.narrow_slices_for(52) == 0 and adj.narrow_slices_for(16) == expect
     bias = torch.randn(16, device=d)
     B = graphgen.random_features(n, 16, seed=77, device=d)
     Ce = adj.matmul_raw(B, bias=bias, relu=True)
