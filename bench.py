@@ -11,9 +11,10 @@ A "step" is one aggregation layer over the whole graph: C = Â·H (N = 1), or, f
 row-block SpMM followed by the exchange of the layer output over xGMI (the next layer's input) — strong
 scaling, the graph is fixed.  For N > 1 every rank builds ITS row block only (graphgen.make_graph_row_block →
 RowShardedAdjacency.from_row_block): no rank ever holds the whole CSR.  Inputs are resident in HBM when the
-timed region starts.  After the timed loop the output of the last step is checked on sampled rows against
-an fp64 evaluation (torch arithmetic, gcn_amd/check.py); the run fails above 1e-5.  Prints ONE JSON line on
-rank 0.
+timed region starts.  After the timed loop the output of the last step (N = 1) — or, on the sharded path, of one more
+layer of the same pipeline run right behind the timed ones, whose input can be kept without copying tens of GB inside
+the timed region — is checked on sampled rows against an fp64 evaluation (torch arithmetic, gcn_amd/check.py); the run
+fails above 1e-5.  Prints ONE JSON line on rank 0.
 
 The other BASELINE configs run through the same code and print the same line (not the headline metric; the
 driver only runs the default):
