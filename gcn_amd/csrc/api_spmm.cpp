@@ -231,7 +231,7 @@ size_t ws_elems(const gcn_spmm_plan* p, int k) {
   int chunks = std::max(p->nchunks, p->panels.out_nchunks);
   chunks = std::max(chunks, p->col16.nchunks16);
   chunks = std::max(chunks, p->group.nchunks);
-  chunks = std::max(chunks, std::max(p->group_alt[0].nchunks, p->group_alt[1].nchunks));
+  chunks = std::max(chunks, p->group_alt[0].nchunks);
   return 2 * (size_t)(chunks > 0 ? chunks : 1) * (size_t)k;
 }
 
@@ -506,7 +506,7 @@ void build_sliced_streams(gcn_spmm_plan* p, hipStream_t st) {
       return;
     }
     p->group = gcn::GroupStream{};
-  for (int c_ = 0; c_ < 2; ++c_) { p->group_alt[c_] = gcn::GroupStream{}; p->alt_S[c_] = 0; p->alt_tried[c_] = false; }
+  for (int c_ = 0; c_ < 1; ++c_) { p->group_alt[c_] = gcn::GroupStream{}; p->alt_S[c_] = 0; p->alt_tried[c_] = false; }
   p->use_alt = -1;
   }
   if (!p->factors.ready()) return;
@@ -765,7 +765,7 @@ int gcn_spmm_plan_enable_slicing(gcn_spmm_plan_t* p, const int32_t* rowptr, cons
   p->slicing = gcn::Slicing{};
   p->col16 = gcn::Col16Stream{};
   p->group = gcn::GroupStream{};
-  for (int c_ = 0; c_ < 2; ++c_) { p->group_alt[c_] = gcn::GroupStream{}; p->alt_S[c_] = 0; p->alt_tried[c_] = false; }
+  for (int c_ = 0; c_ < 1; ++c_) { p->group_alt[c_] = gcn::GroupStream{}; p->alt_S[c_] = 0; p->alt_tried[c_] = false; }
   p->use_alt = -1;
   p->cv.reset();
   const bool autom = slices == -1;
@@ -835,7 +835,7 @@ int gcn_spmm_plan_set_value_factors(gcn_spmm_plan_t* p, const int32_t* rowptr, c
   p->factors = gcn::Factors{};
   p->col16 = gcn::Col16Stream{};                       // (the value-free streams exist only beside factors)
   p->group = gcn::GroupStream{};
-  for (int c_ = 0; c_ < 2; ++c_) { p->group_alt[c_] = gcn::GroupStream{}; p->alt_S[c_] = 0; p->alt_tried[c_] = false; }
+  for (int c_ = 0; c_ < 1; ++c_) { p->group_alt[c_] = gcn::GroupStream{}; p->alt_S[c_] = 0; p->alt_tried[c_] = false; }
   p->use_alt = -1;
   if (!u_row && !u_col) {                                           // (null, null): forget the factors;
     build_sliced_streams(p, (hipStream_t)stream);                   // the sliced plan goes back to its value stream

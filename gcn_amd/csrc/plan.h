@@ -162,9 +162,9 @@ struct gcn_spmm_plan {
   // class 0: k <= 32, a row of the table is 128 bytes, so half as many slices fill an L2 and the partial rows (whose cost
   // goes with the slice count) halve.  (Class 1, 33..48 on 192-byte rows, was measured and is not built.)  Built at the
   // first call of the class (api_spmm.cpp, maybe_build_alt); `use_alt`: the set the call in progress runs on (-1: the plan's own).
-  gcn::GroupStream group_alt[2];
-  int alt_S[2] = {0, 0};
-  bool alt_tried[2] = {false, false};
+  gcn::GroupStream group_alt[1];                    // (indexed by width class; one class so far)
+  int alt_S[1] = {0};
+  bool alt_tried[1] = {false};
   int use_alt = -1;
   gcn::Factors factors;
   gcn::Panels panels;
