@@ -1,6 +1,6 @@
 // spmm_group.hip — the sliced main pass as FOUR independent 16-lane row engines per wave.
 //
-// Why (profiles/r02c_pmc_main_kernel.txt, Reddit-shaped k = 128, 8 slices): the four-per-gather kernel
+// Why (profiles/r02c_pmc_quad_kernel_reddit_k128_S8.txt, Reddit-shaped k = 128, 8 slices): the four-per-gather kernel
 // of spmm_quad.hip keeps one row per WAVE — its four 16-lane groups hold four interleaved partial sums of
 // the same row — so every row end costs a cross-lane reduction, a scalar walk over the 64-entry block with
 // per-lane masks, and scalar row-pointer loads.  With 8 column slices a virtual row is 62 entries long, so
