@@ -58,6 +58,7 @@ FABRIC_GATHER_CEILING = 8.6e12
 K_FEAT = {"reddit": 128, "products": 256, "rmat24": 512, "papers100m": 128}     # BASELINE.json configs 2-5
 ORDER = {"reddit": "none", "products": "rcm", "rmat24": "none", "papers100m": "none"}
 TOL = 1e-5
+FULL_CHECK_MAX_N = 3_000_000      # "fp64 ... on the full matrix for n <= 3 M, on a fixed random sample of 4 096 rows otherwise"
 CPU_SAMPLE_WORK = 1.6e10          # nnz x k of the CPU-baseline sample: about 10 s per torch.spmm on the box's host
 PAPERS_N, PAPERS_SAMPLES = 111059956, 1615685872
 
@@ -362,10 +363,13 @@ def main():
     # ---- the output that was timed, checked on sampled rows against fp64 (every rank its own rows) --------
     gsel = torch.Generator(device="cpu")
     gsel.manual_seed(1234 + rank)
-    nsample = min(4096 if world == 1 else 1024, local_m)
-    sel = torch.randperm(local_m, generator=gsel)[:nsample].sort().values
+    # BASELINE.md §3 / SURVEY §8(d): the FULL matrix for n <= 3 M (every output row of every rank), a fixed random sample of
+    # rows beyond (4 096 on one GPU)
+    full_check = n <= FULL_CHECK_MAX_N
+    nsample = local_m if full_check else min(4096 if world == 1 else 1024, local_m)
+    sel = torch.arange(local_m) if full_check else torch.randperm(local_m, generator=gsel)[:nsample].sort().values
     if not sharded:
-        rel, checked = sampled_rows_rel_err(rowptr, col, val, H, out, sel)
+        rel, checked = sampled_rows_rel_err(rowptr, col, val, H, out, sel, batch_nnz=1 << 22)
     else:
         op_rp, op_col, op_val = shard.as_buffer_operator()      # the layer as a map between exchange buffers
         own = shard.buffer_rows_of_local_rows(dev)
@@ -439,9 +443,15 @@ def main():
         flops = 2.0 * nnz * k if not sim else 2.0 * local_nnz * k
         ord_txt = {"none": "no reorder", "deg": "degree-descending order (order_deg)", "rcm": "RCM order (order_rcm)",
                    "gorder": "Gorder (RCM then Gorder, window 3)"}[order]
-        gname = (f"R-MAT scale {args.rmat_scale} (Graph500 a,b,c,d = .57,.19,.19,.05, edge factor 16"
+        gname = (f"R-MAT scale {args.rmat_scale} (Graph500 a,b,c,d = .57,.19,.19,.05, edge factor 16, seed 5, labels permuted with seed 1005"
                  + (", CPU generator" if args.graph_device == "cpu" else "") + ")") if args.graph == "rmat24" \
-            else f"{args.graph}-shaped R-MAT graph"
+            else (f"{args.graph}-shaped R-MAT graph (gcn_amd.graphgen.make_graph: a,b,c,d = "
+                  + ",".join(f"{x:g}" for x in graphgen.SHAPES[args.graph]["abcd"]) + f", {graphgen.SHAPES[args.graph]['edges']} distinct "
+                  "undirected edges, seed 1, vertex labels randomly permuted with seed 1001, symmetrised, + I, "
+                  "D^-1/2 (A+I) D^-1/2; the milder skew than SURVEY §8(d)'s .57,.19,.19,.05 is deliberate, graphgen.py:18-21)")
+        if papers:
+            gname = (f"papers100M-shaped R-MAT graph (graphgen.make_rmat_row_block: a,b,c,d = .57,.19,.19,.05, {PAPERS_SAMPLES} directed "
+                     "samples, seed 4, labels permuted with seed 1004)")
         line = {
             "metric": "SpMM GFLOP/s + achieved HBM GB/s, Reddit feat=128, 1/2/4/8 MI355X",
             "value": round(flops * args.steps / elapsed / 1e9, 2),
@@ -469,7 +479,9 @@ def main():
             },
             "check": {"rel_err": rel_all, "tol": TOL, "rows_per_rank": int(checked), "passed": not check_failed,
                       "what": ("the layer right behind the timed ones (same pipeline, outside the clock)" if sharded else "last timed step's output")
-                              + " vs fp64 evaluation of sampled rows (torch, gcn_amd/check.py), max over ranks"},
+                              + (" vs fp64 evaluation of EVERY output row (n <= 3 M: the full matrix" if full_check else
+                                 " vs fp64 evaluation of sampled rows (n > 3 M") + "; torch, gcn_amd/check.py), max over ranks",
+                      "rows_total": int(local_m), "full_matrix": bool(full_check)},
             "roofline": {
                 "bound": "l2" if l2_bound else "hbm",
                 "kernel": kname,

@@ -73,6 +73,8 @@ SIGNATURES = {
     "gorder": (None, [_c_p, _c_p, _c_p, _c_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "perm_apply": (None, [_c_p, _c_p, _c_p, _c_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "rabbit": (None, [_c_p, _c_p, _c_p, _c_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "csr2seg_Cmajor": (None, [ctypes.c_int, _c_p, _c_p, _c_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_p, _c_p, _c_p, _c_p,
+                              ctypes.c_int, _c_p]),
     "csr2tile": (None, [_c_p, _c_p, _c_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_p, _c_p, _c_p,
                         _c_p, _c_p, _c_p, ctypes.c_int, _c_p]),
     "flexspmm": (None, [_c_p, _c_p, _c_p, _c_p, _c_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,

@@ -301,6 +301,17 @@ __global__ void dropin_guard_kernel(const int* __restrict__ hdr, int S, int w, i
 }
 }  // namespace
 
+// tile.so also exports the per-panel helper csr2tile loops over (tile.cu:11-12).  Nothing binds it (gcn6.py calls
+// csr2tile only, gcn6.py:341-352), and this library's packing has no per-panel step: the symbol exists so that a
+// loader that resolves every symbol of tile.so finds it; a call says so and returns with every buffer untouched.
+void csr2seg_Cmajor(int ridx, int* rowPtr, int* colIdx, float* vals, int m, int n, int nnz, int* voMp, int* segVoMap,
+                    int* seg_rowPtr, float* segNzCV, int tm, int* n_segs) {
+  (void)ridx; (void)rowPtr; (void)colIdx; (void)vals; (void)m; (void)n; (void)nnz; (void)voMp; (void)segVoMap;
+  (void)seg_rowPtr; (void)segNzCV; (void)tm; (void)n_segs;
+  std::fprintf(stderr, "libgcnspmm: csr2seg_Cmajor: the per-panel step of the reference's tile-seg format (tile.cu:11-103) has no "
+                       "counterpart in this library; call csr2tile. Nothing written\n");
+}
+
 void csr2tile(int* rowPtr, int* colIdx, float* vals, int m, int n, int nnz, int* vo_mp,
               int* segVoMap, int* seg_rowPtr, float* segNzCV, int* grouped_tailSeg, int* next_seg,
               int tm, int* n_segs) {

@@ -235,6 +235,19 @@ size_t ws_elems(const gcn_spmm_plan* p, int k) {
   return 2 * (size_t)(chunks > 0 ? chunks : 1) * (size_t)k;
 }
 
+// rows of a CSR without an entry (the main kernels skip them, launch_fill_empty_rows writes them); synchronises `st`
+int count_empty(const int* rowptr, int m, int* out, hipStream_t st) {
+  gcn::DevBuf<int> cnt;
+  *out = -1;
+  if (cnt.alloc(1) != hipSuccess) return GCN_ERR_ALLOC;
+  int host = 0;
+  if (hipMemsetAsync(cnt, 0, sizeof(int), st) != hipSuccess || gcn::launch_count_empty_rows(rowptr, m, cnt, st) != hipSuccess ||
+      hipMemcpyAsync(&host, cnt, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+    return GCN_ERR_HIP;
+  *out = host;
+  return GCN_OK;
+}
+
 // grow-only scratch of a plan; plans may be shared between host threads, so growth is serialised
 template <class T>
 int grow(gcn::DevBuf<T>& buf, size_t count) {
@@ -359,6 +372,7 @@ int spmm_impl(gcn_spmm_plan* p, const int32_t* rowptr, const int32_t* col, const
   a.chunk_row = p->chunk_row; a.bias = bias; a.relu = relu;
   a.nchunks = p->nchunks; a.T = p->T; a.m = p->m; a.nnz = p->nnz; a.k = k; a.n = p->n;
   a.nnz_dev = nullptr; a.nchunks_grid = p->nchunks;
+  a.empty_rows = p->empty_rows;
   // (which widths run on the sliced copy: sliced_for)
   const bool sliced = sliced_for(p, k);
   // Feature rows that are not a whole number of 128-byte cache lines straddle lines: a gathered row
@@ -405,6 +419,7 @@ int spmm_impl(gcn_spmm_plan* p, const int32_t* rowptr, const int32_t* col, const
     }
     a.nchunks = pn.out_nchunks; a.nchunks_grid = pn.out_nchunks;
     a.T = pn.out_T; a.nnz = pn.out_nnz;
+    a.empty_rows = -1;                                 // (rows whose entries all sit inside their window: not counted)
     a.ev_start = nullptr; a.ev_stop = ev1;
     if (pn.out_S > 0) {
       // sliced: partial rows of the virtual CSR, then C += sum of the partials (+ epilogue)
@@ -459,6 +474,7 @@ int spmm_impl(gcn_spmm_plan* p, const int32_t* rowptr, const int32_t* col, const
   }
   a.rowptr = sl.vrowptr; a.col = sl.vcol; a.val = sl.vval; a.chunk_row = sl.vchunk_row;
   a.C = p->cv; a.m = sl.S * p->m; a.bias = nullptr; a.relu = 0;
+  a.empty_rows = sl.empty_vrows;
   a.stream_rows = gcn::quad_stream_rows() ? 1 : 0;
   const float* rowscale = nullptr;
   if (valless) {                                                          // B was scaled by u_col above
@@ -468,6 +484,7 @@ int spmm_impl(gcn_spmm_plan* p, const int32_t* rowptr, const int32_t* col, const
       a.rowptr = c16.vrowptr16; a.col = reinterpret_cast<const int*>(c16.vcol16.get()); a.chunk_row = c16.vchunk_row16;
       a.nnz = c16.nnz16; a.nchunks = a.nchunks_grid = c16.nchunks16;
       a.col16 = 1; a.col16_S = sl.S; a.col16_w = (p->n + sl.S - 1) / sl.S;
+      a.empty_rows = -1;                                                  // (its own row pointer: not counted)
       for (int i = 0; i < 9; ++i) a.col16_start[i] = c16.start16[i];
     }
   }
@@ -568,7 +585,7 @@ int gcn_spmm_plan_create(gcn_spmm_plan_t** out, const int32_t* rowptr_dev, int32
     if (p->chunk_row.alloc((size_t)p->nchunks) != hipSuccess) { delete p; return GCN_ERR_ALLOC; }
     // (synchronised: the header promises that rowptr_dev is only read during this call)
     if (gcn::launch_plan_chunk_rows(rowptr_dev, m, p->T, p->nchunks, p->chunk_row, (hipStream_t)stream) != hipSuccess ||
-        hipStreamSynchronize((hipStream_t)stream) != hipSuccess) {
+        count_empty(rowptr_dev, m, &p->empty_rows, (hipStream_t)stream) != GCN_OK) {
       delete p;
       return GCN_ERR_HIP;
     }
@@ -814,7 +831,7 @@ int gcn_spmm_plan_enable_slicing(gcn_spmm_plan_t* p, const int32_t* rowptr, cons
     return GCN_ERR_HIP;
   if (!sorted) return autom ? GCN_OK : GCN_ERR_INVALID_ARG;   // needs column-sorted rows; auto mode just stays unsliced
   if (gcn::launch_plan_chunk_rows(sl.vrowptr, (int)vm, p->T, p->nchunks, sl.vchunk_row, st) != hipSuccess ||
-      hipStreamSynchronize(st) != hipSuccess)
+      count_empty(sl.vrowptr, (int)vm, &sl.empty_vrows, st) != GCN_OK)
     return GCN_ERR_HIP;
   sl.S = slices;
   p->slicing = std::move(sl);

@@ -88,6 +88,7 @@ class EventPairs {
 // XCD-aware column slicing (slicing.hip): slice-major copy of the matrix with S*m virtual rows
 struct Slicing {
   int S = 0;                                        // 0 = off
+  int empty_vrows = -1;                             // empty rows of the virtual CSR (SpmmArgs::empty_rows), -1: not counted
   DevBuf<int> vrowptr;                              // [S*m+1]
   DevBuf<int> vcol;                                 // [nnz]
   DevBuf<float> vval;                               // [nnz]
@@ -144,6 +145,7 @@ struct Panels {
 struct gcn_spmm_plan {
   int32_t m = 0, n = 0, nnz = 0, T = 0, nchunks = 0;
   int cu_count = 0, device = 0;
+  int empty_rows = -1;                              // rows without an entry (counted at plan creation; -1: unknown): SpmmArgs::empty_rows
   gcn::DevBuf<int> chunk_row;                       // [nchunks]
   gcn::DevBuf<float> ws;                            // partial slab [2*chunks x k], grow-only
   gcn::DevBuf<float> cv;                            // partial outputs [S*m x k], grow-only

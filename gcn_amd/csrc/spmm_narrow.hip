@@ -73,7 +73,7 @@ spmm_narrow_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
       for (int off = G; off < 64; off <<= 1) t += __shfl_xor(t, off);
       if (head) {
         if (sub == 0 && fok) P[(size_t)(2 * c) * k + f] = t;
-      } else {
+      } else if (last_flush != pos) {               // (empty rows belong to launch_fill_empty_rows, spmm_kernels.hip)
         if (EPI) {
           t += bias_f;
           if (relu) t = fmaxf(t, 0.f);
@@ -85,6 +85,10 @@ spmm_narrow_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
       last_flush = pos;
       ++r;
       row_end    = row_end_nx;
+      if (row_end == pos) {                         // row r is empty: jump over the whole run of empty rows
+        r = next_nonempty_row(rowptr, r, m, pos);
+        row_end = (r < m) ? rowptr[r + 1] : -1;
+      }
       row_end_nx = (r + 1 < m) ? rowptr[r + 2] : -1;
     };
 
@@ -217,7 +221,7 @@ spmm_narrow16_dpp_kernel(const int* __restrict__ rowptr, const int* __restrict__
       t += __shfl_xor(t, 32);
       if (head) {
         if (sub == 0 && fok) P[(size_t)(2 * c) * k + f] = t;
-      } else {
+      } else if (last_flush != pos) {               // (empty rows belong to launch_fill_empty_rows, spmm_kernels.hip)
         if (EPI) {
           t += bias_f;
           if (relu) t = fmaxf(t, 0.f);
@@ -229,6 +233,10 @@ spmm_narrow16_dpp_kernel(const int* __restrict__ rowptr, const int* __restrict__
       last_flush = pos;
       ++r;
       row_end    = row_end_nx;
+      if (row_end == pos) {                         // row r is empty: jump over the whole run of empty rows
+        r = next_nonempty_row(rowptr, r, m, pos);
+        row_end = (r < m) ? rowptr[r + 1] : -1;
+      }
       row_end_nx = (r + 1 < m) ? rowptr[r + 2] : -1;
     };
     // one step = the 4 non-zeros at [pos, pos + n_step)

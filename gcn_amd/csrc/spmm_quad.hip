@@ -147,7 +147,7 @@ spmm_quad_kernel(const int* __restrict__ g_rowptr, const int* __restrict__ g_col
       float4 t = quad_reduce<LPE>(acc);
       if (head) {
         if (writer) *reinterpret_cast<float4*>(a.P + (size_t)(2 * c) * kk + fcol) = t;
-      } else {
+      } else if (last_flush != pos) {               // (empty rows belong to launch_fill_empty_rows, spmm_kernels.hip)
         float4* dst = reinterpret_cast<float4*>(a.C + (size_t)r * kk + fcol);
         if (accumulate) {
           if (writer) { const float4 o = *dst; t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w; }
@@ -166,6 +166,10 @@ spmm_quad_kernel(const int* __restrict__ g_rowptr, const int* __restrict__ g_col
       last_flush = pos;
       ++r;
       row_end    = row_end_nx;
+      if (row_end == pos) {                         // row r is empty: jump over the whole run of empty rows
+        r = next_nonempty_row(a.rowptr, r, m, pos);
+        row_end = (r < m) ? a.rowptr[r + 1] : -1;
+      }
       row_end_nx = (r + 1 < m) ? a.rowptr[r + 2] : -1;
     };
     while (pos == row_end) flush();                 // leading empty rows (chunk 0 only)

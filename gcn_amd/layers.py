@@ -145,7 +145,15 @@ class GCN(nn.Module):
         # restarts differ unless seeded alike), the offset counts forward passes; both are part of state_dict-less
         # extra state (get_extra_state) so a checkpoint resumes the same mask sequence
         self.dropout_seed, self._dropout_calls = None, 0
+        # ... and OPTIONAL on load: a reference-format checkpoint holds the four weight tensors only
+        # (profiling_gcn.py:165-170: torch.save(model.state_dict()) / load_state_dict), as do checkpoints of this class
+        # written before the extra state existed; a strict load of those must not fail on a missing "_extra_state"
+        self._register_load_state_dict_pre_hook(self._default_extra_state)
         self.dur_fwd = timers.Timer()
+
+    @staticmethod
+    def _default_extra_state(state_dict, prefix, *_unused):
+        state_dict.setdefault(prefix + "_extra_state", {"dropout_seed": None, "dropout_calls": 0})
 
     def reset_timing(self):
         self.dur_fwd.reset()

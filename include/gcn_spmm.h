@@ -327,6 +327,12 @@ void csr2tile(int* rowPtr, int* colIdx, float* vals, int m, int n, int nnz,
               int* vo_mp, int* segVoMap, int* seg_rowPtr, float* segNzCV,
               int* grouped_tailSeg, int* next_seg, int tm, int* n_segs);
 
+/* tile.so — tile.cu:11-12: the per-panel helper csr2tile loops over in the reference, exported there as well.  No call
+ * site binds it (gcn6.py:341-352 calls csr2tile only) and this library's packing has no per-panel step: the symbol
+ * resolves, prints one line to stderr and returns with every buffer (n_segs included) untouched. */
+void csr2seg_Cmajor(int ridx, int* rowPtr, int* colIdx, float* vals, int m, int n, int nnz,
+                    int* voMp, int* segVoMap, int* seg_rowPtr, float* segNzCV, int tm, int* n_segs);
+
 /* flexspmm.so — flexspmm.cu:499-502.  All pointers DEVICE.  Consumes the arrays
  * written by this library's csr2tile (plain CSR, or — square graphs that qualify for XCD-aware slicing — the group
  * kernels' stream format).  Like the reference's (flexspmm.cu:497-540) the call only ENQUEUES

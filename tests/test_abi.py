@@ -32,9 +32,10 @@ def test_header_symbols_are_exported():
 
 @pytest.mark.parametrize("name", ["flexspmm.so", "cuspmm.so", "tile.so", "permutate.so", "renumber.so"])
 def test_dropin_objects_carry_the_reference_symbols(name):
-    """gcn6.py:21-25 loads these five file names; each must resolve the symbols gcn6 calls."""
+    """gcn6.py:21-25 loads these five file names; each must resolve the symbols gcn6 calls (and the one other `extern "C"`
+    symbol the reference's objects export: csr2seg_Cmajor, tile.cu:11)."""
     lib = ctypes.CDLL(os.path.join(gcn_amd.DROPIN_DIR, name))
-    wanted = {"flexspmm.so": ["flexspmm"], "cuspmm.so": ["cuspmm"], "tile.so": ["csr2tile"],
+    wanted = {"flexspmm.so": ["flexspmm"], "cuspmm.so": ["cuspmm"], "tile.so": ["csr2tile", "csr2seg_Cmajor"],
               "permutate.so": ["permutate"], "renumber.so": ["dfs", "gorder", "rabbit", "perm_apply"]}[name]
     for sym in wanted:
         assert hasattr(lib, sym)
@@ -215,3 +216,15 @@ def test_csr2tile_group_format_is_the_matrix():
         cut = cut[first_of_row[vrow[starts[cut]]] // 512 == cut - 1]
         assert hd["nfix"] == len(cut) and np.array_equal(np.sort(fix[:, 1]), cut)
         assert np.array_equal(fix[np.argsort(fix[:, 1]), 0], vrow[starts[cut]])
+
+
+def test_csr2seg_cmajor_resolves_prints_and_touches_nothing(capfd):
+    """tile.cu:11-12 exports it beside csr2tile; no call site binds it: ours says so on stderr and returns"""
+    lib = gcn_amd.load_library()
+    rp = np.array([0, 2, 3], np.int32); ci = np.array([0, 1, 1], np.int32); va = np.ones(3, np.float32)
+    bufs = [np.full(16, 7, np.int32) for _ in range(3)] + [np.full(16, 7.0, np.float32)]
+    nseg = np.array([-5], np.int32)
+    vp = lambda a: ctypes.c_void_p(a.ctypes.data)
+    lib.csr2seg_Cmajor(0, vp(rp), vp(ci), vp(va), 2, 2, 3, vp(bufs[0]), vp(bufs[1]), vp(bufs[2]), vp(bufs[3]), 8, vp(nseg))
+    assert "csr2seg_Cmajor" in capfd.readouterr().err
+    assert nseg[0] == -5 and all(np.all(b == 7) for b in bufs)

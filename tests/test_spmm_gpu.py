@@ -334,7 +334,7 @@ def test_reorder_then_spmm_is_a_permutation_of_the_result():
 # --- BASELINE-size checks through size-independent properties ---------------------------------
 def test_full_size_reddit_shape_properties():
     """Reddit-shaped graph at full size (n = 232 965, nnz ≈ 114.85 M, k = 128):
-    (i) sampled rows against the fp64 oracle, (ii) Â·1 = row sums, (iii) linearity."""
+    (i) sampled rows against the fp64 C oracle and ALL rows against fp64 on the device, (ii) Â·1 = row sums, (iii) linearity."""
     d = _dev()
     rowptr, col, val, n = graphgen.make_graph("reddit", device=d, seed=1)
     nnz = int(col.numel())
@@ -351,6 +351,11 @@ def test_full_size_reddit_shape_properties():
     sub_rp = np.zeros(len(rows) + 1, np.int32); sub_rp[1:] = np.cumsum([len(s) for s in seg])
     Cref = oracle_spmm(sub_rp, col[idx].cpu().numpy(), val[idx].cpu().numpy(), B.cpu().numpy())
     assert rel_err(C[torch.from_numpy(rows).to(d)].cpu().numpy(), Cref) <= TOL
+    # (i') the FULL matrix, every one of the 232 965 rows, against an fp64 evaluation on the device in blocks of rows
+    # ("full matrix for n <= 3 M"; gcn_amd/check.py: plain torch arithmetic, no library code)
+    from gcn_amd.check import sampled_rows_rel_err
+    rel, checked = sampled_rows_rel_err(rowptr, col, val, B, C, torch.arange(n), batch_nnz=1 << 22)
+    assert checked == n and rel <= TOL, rel
     # (ii) Â·1: every output column equals the row sum of Â
     ones = torch.ones((n, 64), device=d)
     rs = adj.matmul_raw(ones)
