@@ -17,6 +17,7 @@ class GcnAmdError(RuntimeError):
 
 
 ERR_NOT_FACTORED = 6         # GCN_ERR_NOT_FACTORED
+ERR_INTERNAL = 7             # GCN_ERR_INTERNAL (a consistency guard tripped: gcn_order_rabbit_device)
 
 
 _c_i32 = ctypes.c_int32

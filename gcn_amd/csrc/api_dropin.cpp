@@ -293,11 +293,14 @@ __host__ __device__ inline bool dropin_header_ok(const int* h, int S, int w, int
 }
 
 // dyn = {buffers recognised, chunk count, cut rows, 0}: what the kernels of this call read instead of host arguments
+// refused: a word in host-mapped memory that counts the calls whose header no longer matched ON THE DEVICE — the host
+// looks at it at the start of the next flexspmm (a plain memory read, no synchronisation) and reports what it finds
 __global__ void dropin_guard_kernel(const int* __restrict__ hdr, int S, int w, int value_free, int nchunks_ub,
-                                    int* __restrict__ dyn) {
+                                    int* __restrict__ dyn, int* __restrict__ refused) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   const bool ok = dropin_header_ok(hdr, S, w, value_free, nchunks_ub);
   dyn[0] = ok ? 1 : 0; dyn[1] = ok ? hdr[4] : 0; dyn[2] = ok ? hdr[5] : 0; dyn[3] = 0;
+  if (!ok && refused) __hip_atomic_fetch_add(refused, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 }  // namespace
 
@@ -377,8 +380,30 @@ static void flexspmm_group(const int* seg_rowPtr, const float* segNzCV, const in
   std::lock_guard<std::mutex> lk(gcn::g_plan_mu);
   // First sight of these buffers: read the 64-byte header once (synchronous, legacy stream) so that buffers this
   // library did not pack are REPORTED; afterwards only the device-side guard looks at it.
+  // Afterwards a set of buffers whose content changed under the same addresses is refused by the device-side guard alone;
+  // that guard counts its refusals in a host-mapped word, read here at the NEXT call: the refusal is reported one call
+  // late instead of never, and every remembered set of buffers is forgotten, so each gets its header read again.
+  static int* refused_host = nullptr;
+  static int* refused_dev = nullptr;
+  static int refused_reported = 0;
   {
     static auto* seen = new std::set<std::tuple<const void*, const void*, const void*, int, int, int>>();
+    if (!refused_host) {                                 // (best effort: without the mailbox the guard still refuses, silently)
+      int* h = nullptr;
+      if (hipHostMalloc((void**)&h, 64, hipHostMallocMapped) == hipSuccess) {
+        h[0] = 0;
+        if (hipHostGetDevicePointer((void**)&refused_dev, h, 0) == hipSuccess) refused_host = h; else (void)hipHostFree(h);
+      }
+    }
+    if (refused_host) {
+      const int now = *(volatile int*)refused_host;
+      if (now != refused_reported) {
+        std::fprintf(stderr, "libgcnspmm: flexspmm: %d earlier call(s) were refused on the device: the packed header no longer matched "
+                             "(buffers rewritten under the same addresses?); their C was left untouched\n", now - refused_reported);
+        refused_reported = now;
+        seen->clear();
+      }
+    }
     const auto key = std::make_tuple((const void*)seg_rowPtr, (const void*)segNzCV, (const void*)segVoMap, m, n, n_segs);
     if (!seen->count(key)) {
       int h[16];
@@ -410,7 +435,7 @@ static void flexspmm_group(const int* seg_rowPtr, const float* segNzCV, const in
   if (kc != k) FLEX_TRY(scratch.cpad.grow((size_t)m * (size_t)kc), "padded result allocation");
   hipStream_t st = nullptr;                                        // legacy default stream (flexspmm.cu:512)
   int* dyn = scratch.dyn;
-  dropin_guard_kernel<<<1, 64, 0, st>>>(seg_rowPtr, g.S, g.w, value_free, g.nchunks_ub, dyn);
+  dropin_guard_kernel<<<1, 64, 0, st>>>(seg_rowPtr, g.S, g.w, value_free, g.nchunks_ub, dyn, refused_dev);
   FLEX_TRY(hipGetLastError(), "guard launch");
   const float* u = value_free ? reinterpret_cast<const float*>(segVoMap) : nullptr;
   FLEX_TRY(gcn::launch_scale_rows_sliced(scratch.bpad, B, u, n, k, ldb, g.S, g.w, st), "feature copy");

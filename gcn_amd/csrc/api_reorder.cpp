@@ -75,9 +75,10 @@ int gcn_csr_apply_rank_device(const int32_t* rowptr_dev, const int32_t* col_dev,
 int gcn_order_rabbit_device(const int32_t* rowptr_dev, const int32_t* col_dev, int32_t n, int32_t nnz,
                             int32_t* rank_out_dev, int32_t* community_out_dev, int64_t* stats_host, void* stream) {
   if (n < 0 || nnz < 0 || (n > 0 && (!rowptr_dev || !rank_out_dev)) || (nnz > 0 && !col_dev)) return GCN_ERR_INVALID_ARG;
-  long long st4[4] = {0, 0, 0, 0};
-  const hipError_t e = gcn::device_order_rabbit(rowptr_dev, col_dev, n, nnz, rank_out_dev, community_out_dev, st4, (hipStream_t)stream);
-  if (stats_host) for (int i = 0; i < 4; ++i) stats_host[i] = (int64_t)st4[i];
+  long long st8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const hipError_t e = gcn::device_order_rabbit(rowptr_dev, col_dev, n, nnz, rank_out_dev, community_out_dev, st8, (hipStream_t)stream);
+  if (stats_host) for (int i = 0; i < 8; ++i) stats_host[i] = (int64_t)st8[i];
+  if (e == hipErrorAssert) return GCN_ERR_INTERNAL;      // a loop guard tripped (stats_host[4..7]): no ordering was written
   return e == hipSuccess ? GCN_OK : (e == hipErrorOutOfMemory ? GCN_ERR_ALLOC : GCN_ERR_HIP);
 }
 

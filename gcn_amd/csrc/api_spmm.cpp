@@ -560,6 +560,7 @@ const char* gcn_status_string(int s) {
     case GCN_ERR_CAPACITY: return "caller buffer too small";
     case GCN_ERR_ALLOC: return "device allocation failed";
     case GCN_ERR_NOT_FACTORED: return "values do not factor as u_row[r]*u_col[c]";
+    case GCN_ERR_INTERNAL: return "internal consistency guard tripped";
     default: return "unknown status";
   }
 }

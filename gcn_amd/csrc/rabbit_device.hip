@@ -352,10 +352,13 @@ struct Dev {                                             // scoped device buffer
 }  // namespace
 
 // rank_out_dev [n] (rank[old] = new), community_out_dev [n] or null (top-level vertex of every vertex),
-// stats_host[4] or null: {communities, passes, retried vertices, vertices left top-level for lack of table / pool room}
+// stats_host[8] or null: {communities, passes, retried vertices, vertices left top-level for lack of table / pool room,
+// guard trips: pointer chain, child chain, full table, bad index}.  The four guards bound loops that end by themselves
+// in a sound run; a trip means an aggregation was cut short on broken state (a cyclic child list, a stale index): the
+// ordering is then NOT returned — hipErrorAssert, one line on stderr, the counts in stats_host.
 hipError_t device_order_rabbit(const int* rowptr, const int* col, int n, int nnz, int* rank_out_dev, int* community_out_dev,
                                long long* stats_host, hipStream_t st) {
-  if (stats_host) stats_host[0] = stats_host[1] = stats_host[2] = stats_host[3] = 0;
+  if (stats_host) for (int i = 0; i < 8; ++i) stats_host[i] = 0;
   if (n <= 0) return hipSuccess;
 #define GCN_R(x) do { const hipError_t e_ = (x); if (e_ != hipSuccess) return e_; } while (0)
   int cu = 256;
@@ -387,6 +390,8 @@ hipError_t device_order_rabbit(const int* rowptr, const int* col, int n, int nnz
   GCN_R(hipMemcpyAsync(&two_m, scal.p, sizeof(two_m), hipMemcpyDeviceToHost, st));
   GCN_R(hipStreamSynchronize(st));
   long long passes = 0, retried = 0;
+  unsigned guards[4] = {0, 0, 0, 0};                     // the counters cnt[4..7] as last read back (they only grow)
+  struct SideStream { hipStream_t s = nullptr; ~SideStream() { if (s) (void)hipStreamDestroy(s); } } side_owner;
   const bool verbose = [] { const char* e = getenv("GCN_AMD_VERBOSE"); return e && e[0] && e[0] != '0'; }();
   if (verbose) { std::fprintf(stderr, "rabbit_device: n=%d nnz=%d 2m=%llu waves=%d\n", n, nnz, two_m, nwaves); std::fflush(stderr); }
   if (two_m > 0) {
@@ -413,6 +418,7 @@ hipError_t device_order_rabbit(const int* rowptr, const int* col, int n, int nnz
       GCN_R(beat.alloc((size_t)nwaves * 4));
       GCN_R(hipMemsetAsync(beat.p, 0, sizeof(unsigned) * (size_t)nwaves * 4, st));
       GCN_R(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+      side_owner.s = side;                               // (destroyed on every way out)
       a.beat = beat.p;
     }
     void* sort_tmp = nullptr;
@@ -460,6 +466,7 @@ hipError_t device_order_rabbit(const int* rowptr, const int* col, int n, int nnz
                              "child chain %u, table %u, index %u\n", passes + 1, count, h[1], h[2], h[4], h[5], h[6], h[7]);
         std::fflush(stderr);
       }
+      for (int g = 0; g < 4; ++g) guards[g] = h[4 + g];
       count = h[1];
       retried += count;
       unsigned* t = cur; cur = nxt; nxt = t;
@@ -475,6 +482,15 @@ hipError_t device_order_rabbit(const int* rowptr, const int* col, int n, int nnz
   GCN_R(hipMemcpyAsync(h_sib.data(), sibling.p, sizeof(unsigned) * (size_t)n, hipMemcpyDeviceToHost, st));
   GCN_R(hipMemcpyAsync(&h_skipped, cnt.p + 2, sizeof(unsigned), hipMemcpyDeviceToHost, st));
   GCN_R(hipStreamSynchronize(st));
+  if (stats_host) {
+    stats_host[1] = passes; stats_host[2] = retried; stats_host[3] = (long long)h_skipped;
+    for (int g = 0; g < 4; ++g) stats_host[4 + g] = (long long)guards[g];
+  }
+  if (guards[0] | guards[1] | guards[2] | guards[3]) {
+    std::fprintf(stderr, "libgcnspmm: rabbit_device: guard trips (pointer chain %u, child chain %u, full table %u, bad index %u): "
+                         "an aggregation ran on broken state; no ordering returned\n", guards[0], guards[1], guards[2], guards[3]);
+    return hipErrorAssert;
+  }
   std::vector<int> rank((size_t)n), comm((size_t)n);
   std::vector<unsigned> stack, kids;
   long long ncomm = 0;
@@ -499,7 +515,7 @@ hipError_t device_order_rabbit(const int* rowptr, const int* col, int n, int nnz
   GCN_R(hipMemcpyAsync(rank_out_dev, rank.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice, st));
   if (community_out_dev) GCN_R(hipMemcpyAsync(community_out_dev, comm.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice, st));
   GCN_R(hipStreamSynchronize(st));
-  if (stats_host) { stats_host[0] = ncomm; stats_host[1] = passes; stats_host[2] = retried; stats_host[3] = (long long)h_skipped; }
+  if (stats_host) stats_host[0] = ncomm;
 #undef GCN_R
   return hipSuccess;
 }

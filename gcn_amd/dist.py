@@ -75,7 +75,7 @@ class RowShardedAdjacency:
     """
 
     def __init__(self, rowptr, col, val, n, rank, world, make_local, balance="nnz", value_factor=None,
-                 exchange="all_gather", prelaid="auto", plane_cols=64):
+                 exchange="all_gather", prelaid="auto", plane_cols=64, group=None):
         """Whole-graph convenience constructor: every rank passes the same CSR (int32 rowptr/col on the
         device); the partition is derived from it and this rank keeps its block."""
         rowptr_h = rowptr.detach().cpu().numpy().astype(np.int64)
@@ -84,29 +84,39 @@ class RowShardedAdjacency:
         e_lo, e_hi = int(rowptr_h[lo]), int(rowptr_h[hi])
         local_rowptr = torch.from_numpy(rowptr_h[lo:hi + 1] - e_lo).to(col.device)
         self._setup(local_rowptr, col[e_lo:e_hi], val[e_lo:e_hi], bounds, rank, world, make_local,
-                    value_factor, int(rowptr_h[-1]), exchange, prelaid, plane_cols)
+                    value_factor, int(rowptr_h[-1]), exchange, prelaid, plane_cols, group)
         if int(n) != self.n:
             raise ValueError("n does not match the row pointer")
 
     @classmethod
     def from_row_block(cls, local_rowptr, local_col, local_val, bounds, rank, world, make_local,
-                       value_factor=None, total_nnz=None, exchange="all_gather", prelaid="auto", plane_cols=64):
+                       value_factor=None, total_nnz=None, exchange="all_gather", prelaid="auto", plane_cols=64, group=None):
         """A rank from its own row block: `local_rowptr` [rows+1] (starts at 0), `local_col` GLOBAL column
         ids (any integer dtype; int64 for graphs past 2³¹ columns·entries), `local_val` fp32, `bounds`
-        [world+1] the first global row of every rank's block (the same on all ranks)."""
+        [world+1] the first global row of every rank's block (the same on all ranks).  `group`: the process group
+        the shard's layers will run on (None = the default group); its size must be `world`."""
         self = cls.__new__(cls)
         self._setup(local_rowptr, local_col, local_val, np.asarray(bounds, dtype=np.int64), rank, world,
-                    make_local, value_factor, total_nnz, exchange, prelaid, plane_cols)
+                    make_local, value_factor, total_nnz, exchange, prelaid, plane_cols, group)
         return self
 
     def _setup(self, local_rowptr, gcol, val, bounds, rank, world, make_local, value_factor, total_nnz, exchange,
-               prelaid="auto", plane_cols=64):
+               prelaid="auto", plane_cols=64, group=None):
         if exchange not in ("all_gather", "direct"):
             raise ValueError("exchange must be 'all_gather' or 'direct'")
-        self.rank, self.world, self.exchange = int(rank), int(world), exchange
+        self.rank, self.world, self.exchange, self.group = int(rank), int(world), exchange, group
         self.bounds = np.asarray(bounds, dtype=np.int64)
         if len(self.bounds) != self.world + 1 or self.bounds[0] != 0 or np.any(np.diff(self.bounds) < 0):
             raise ValueError("bounds must be world+1 non-decreasing row boundaries starting at 0")
+        # the ranks this shard exchanges with: its process group must have exactly `world` members (size 1: one process
+        # standing in for one rank of `world`, collective = False — nobody to exchange or agree with)
+        peers = False
+        if self.world > 1 and dist.is_available() and dist.is_initialized():
+            gsize = dist.get_world_size(group)
+            if gsize not in (1, self.world):
+                raise ValueError(f"the shard is one of {self.world} but its process group has {gsize} ranks: pass the group "
+                                 "the layers run on (group=...)")
+            peers = gsize == self.world
         self.n = int(self.bounds[-1])
         self.collective = True     # False = compute this rank's block only (single-GPU rehearsal of rank r of W)
         self.max_rows = int(np.diff(self.bounds).max())
@@ -167,15 +177,17 @@ class RowShardedAdjacency:
             ok = (lay is not None and lay["slices"] == self.world * self.slices_per_rank and lay["slice_cols"] == self.slice_cols
                   and lay["ld"] == plane_cols)
             # the ranks must AGREE: a rank whose block falls on the other side of a rule (non-zeros per column, table
-            # sizes) would size its exchange buffers differently and the collective would hang.  One MIN over the ranks.
-            if self.world > 1 and dist.is_available() and dist.is_initialized() and dist.get_world_size() == self.world:
+            # sizes) would size its exchange buffers differently and the collective would hang.  One MIN over the ranks
+            # of the group the layers will run on (the default group is not necessarily that group).
+            if peers:
                 flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
                 ok = bool(int(flag.item()))
             if not ok:
                 if prelaid is True:
                     raise _lib.GcnAmdError(f"prelaid=True: the local operator does not offer the layout (got {lay})")
                 self.prelaid = False                       # (the wider slot stays: harmless for the copying path)
+                self.local = self._new_local()             # ... and the operator goes back to its own slice count
 
     # -- global <-> padded numbering (device side) ---------------------------------------------
     def _pad_index(self, device):
@@ -284,7 +296,7 @@ class RowShardedAdjacency:
         if self.rows:
             self._local_spmm(local or self.local, H_padded, slot)
         if self.world > 1 and self.collective:
-            return self._exchange(out_padded, slot, group, True)
+            return self._exchange(out_padded, slot, group if group is not None else self.group, True)
         return None
 
     def buffer_rows_of_local_rows(self, device):
@@ -328,7 +340,7 @@ class RowShardedAdjacency:
         if self.rows:
             self._local_spmm(self.local, H_padded, slot)
         if self.world > 1 and self.collective:
-            self._exchange(out_padded, slot, group, False)
+            self._exchange(out_padded, slot, group if group is not None else self.group, False)
         return out_padded
 
 

@@ -282,3 +282,93 @@ def make_sbm(n, block=512, deg_in=200, deg_out=46, device="cpu", seed=7, relabel
     keys = torch.unique((lo * n + hi)[lo != hi])
     rowptr, col, val = normalized_adjacency(n, keys, relabel_seed=(seed + 1000) if relabel else None)
     return rowptr, col, val, n
+
+
+def community_sizes(n, communities, skew=1.0, min_size=64, seed=0):
+    """`communities` heterogeneous sizes that sum to n: weights ~ rank^-skew (Zipf; skew 0 = equal sizes), every community
+    at least min_size vertices.  Deterministic (numpy on the host: a few thousand numbers).  → np.int64 [communities]"""
+    import numpy as np
+    communities = int(max(1, min(communities, n // max(1, min_size))))
+    w = np.arange(1, communities + 1, dtype=np.float64) ** -float(skew)
+    np.random.default_rng(seed).shuffle(w)
+    spare = n - communities * min_size
+    sizes = min_size + np.floor(w / w.sum() * spare).astype(np.int64)
+    sizes[: n - int(sizes.sum())] += 1                      # the rounding remainder, one vertex each
+    assert int(sizes.sum()) == n
+    return sizes
+
+
+def make_dcsbm(n=232965, edges=57307946, communities=200, mixing=0.35, max_degree=20000, gamma=2.5, size_skew=1.0,
+               device="cpu", seed=11, relabel=True, return_communities=False):
+    """Degree-corrected planted-partition graph at the headline size: the stand-in for what the
+    reference's datasets look like (run.sh:1-9: reddit, flickr, ppi, yelp, amazon — graphs WITH community structure, which is
+    why gcn6 renumbers by default, gcn6.py:27-30,313-332).  Every vertex has a weight theta (truncated power law: exponent
+    `gamma`, largest ≈ max_degree / mean degree times the mean) and lives in one of `communities` planted communities of
+    heterogeneous size (community_sizes).  An edge sample picks u ~ theta over all vertices, then v ~ theta inside u's
+    community with probability 1 - mixing and over all vertices otherwise; samples are de-duplicated and topped up to
+    exactly `edges` distinct undirected edges, then symmetrised, + I, D^-1/2 (A+I) D^-1/2 like every other graph here,
+    labels randomly permuted (relabel) so that "no reorder" has no locality.
+    → (rowptr, col, val, n[, community of every vertex in the RETURNED numbering (int64)])
+    The realised share of cross-community edges is a little above `mixing` where a hub saturates a small community."""
+    import numpy as np
+    device = torch.device(device)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    sizes = community_sizes(n, communities, size_skew, seed=seed)
+    ncom = len(sizes)
+    start_h = np.zeros(ncom + 1, np.int64)
+    start_h[1:] = np.cumsum(sizes)
+    start = torch.from_numpy(start_h).to(device)
+    comm = torch.repeat_interleave(torch.arange(ncom, device=device), torch.from_numpy(sizes).to(device))   # planted order: by community
+    # weights: theta = (1 - U)^(-1/(gamma-1)), truncated so that the largest expected degree is ~max_degree
+    mean_deg = 2.0 * edges / n
+    u01 = torch.rand(n, generator=gen, device=device, dtype=torch.float64)
+    theta = (1.0 - u01).pow(-1.0 / (gamma - 1.0))
+    cap = float(max_degree) / mean_deg * float(theta.mean())
+    for _ in range(4):                                     # (truncation lowers the mean: re-aim the cap)
+        t = torch.clamp(theta, max=cap)
+        cap = float(max_degree) / mean_deg * float(t.mean())
+    theta = torch.clamp(theta, max=cap)
+    cum = torch.cumsum(theta, 0)
+    total = float(cum[-1])
+    cum0 = torch.cat([torch.zeros(1, dtype=torch.float64, device=device), cum])
+    c_lo, c_hi = cum0[start[:-1]], cum0[start[1:]]         # theta mass in front of / up to the end of every community
+
+    def draw(count):
+        u = torch.searchsorted(cum, torch.rand(count, generator=gen, device=device, dtype=torch.float64) * total).clamp_(max=n - 1)
+        inside = torch.rand(count, generator=gen, device=device) >= mixing
+        cu = comm[u]
+        r = torch.rand(count, generator=gen, device=device, dtype=torch.float64)
+        x = torch.where(inside, c_lo[cu] + r * (c_hi[cu] - c_lo[cu]), r * total)
+        v = torch.searchsorted(cum, x).clamp_(max=n - 1)
+        v = torch.where(inside, torch.minimum(torch.maximum(v, start[cu]), start[cu + 1] - 1), v)   # (rounding at a community's edge)
+        return u, v
+
+    keys = torch.empty(0, dtype=torch.int64, device=device)
+    need = edges
+    for _round in range(64):
+        batch = min(int(need * 1.2) + 1024, 1 << 26)
+        u, v = draw(batch)
+        lo, hi = torch.minimum(u, v), torch.maximum(u, v)
+        ok = lo != hi
+        keys = torch.unique(torch.cat([keys, lo[ok] * n + hi[ok]]))
+        del u, v, lo, hi, ok
+        if keys.numel() >= edges:
+            break
+        need = edges - keys.numel()
+    else:  # pragma: no cover
+        raise RuntimeError("DC-SBM generator did not reach the requested edge count")
+    if keys.numel() > edges:
+        perm = torch.randperm(keys.numel(), generator=gen, device=device)[:edges]
+        keys = keys[perm.sort().values]
+    rowptr, col, val = normalized_adjacency(n, keys, relabel_seed=(seed + 1000) if relabel else None)
+    if not return_communities:
+        return rowptr, col, val, n
+    if relabel:                                            # the same permutation normalized_adjacency drew
+        g2 = torch.Generator(device=device)
+        g2.manual_seed(seed + 1000)
+        perm = torch.randperm(n, generator=g2, device=device)
+        out = torch.empty_like(comm)
+        out[perm] = comm
+        comm = out
+    return rowptr, col, val, n, comm

@@ -185,7 +185,7 @@ def order_rabbit_device(rowptr, col, return_communities=False, return_stats=Fals
     rp, ci = rowptr.to(torch.int32).contiguous(), col.to(torch.int32).contiguous()
     rank = torch.empty(n, dtype=torch.int32, device=rowptr.device)
     comm = torch.empty(n, dtype=torch.int32, device=rowptr.device) if return_communities else None
-    stats = (ctypes.c_int64 * 4)()
+    stats = (ctypes.c_int64 * 8)()
     with torch.cuda.device(rowptr.device):
         _lib.check(_lib.load().gcn_order_rabbit_device(
             ctypes.c_void_p(rp.data_ptr()), ctypes.c_void_p(ci.data_ptr()), n, int(ci.numel()),
@@ -196,7 +196,8 @@ def order_rabbit_device(rowptr, col, return_communities=False, return_stats=Fals
     if return_communities:
         out.append(comm.to(torch.int64))
     if return_stats:
-        out.append(dict(communities=int(stats[0]), passes=int(stats[1]), retried=int(stats[2]), left_top_level=int(stats[3])))
+        out.append(dict(communities=int(stats[0]), passes=int(stats[1]), retried=int(stats[2]), left_top_level=int(stats[3]),
+                        guard_trips=[int(stats[4 + g]) for g in range(4)]))
     return out[0] if len(out) == 1 else tuple(out)
 
 

@@ -37,6 +37,7 @@ extern "C" {
 #define GCN_ERR_CAPACITY       4   /* caller buffer too small for the packed plan */
 #define GCN_ERR_ALLOC          5
 #define GCN_ERR_NOT_FACTORED   6   /* set_value_factors: some stored entry is not u_row[r]*u_col[c]; the plan keeps its value stream */
+#define GCN_ERR_INTERNAL       7   /* a consistency guard inside the library tripped (gcn_order_rabbit_device: stats_host[4..7]); outputs not written */
 
 const char* gcn_status_string(int status);
 /* library version, "major.minor.patch" */
@@ -296,8 +297,11 @@ int gcn_csr_apply_rank_device(const int32_t* rowptr_dev, const int32_t* col_dev,
  * the `rabbit` symbol give those) and not bit-reproducible from run to run (which merges race differs): what is
  * guaranteed is a permutation whose communities reach the serial version's modularity to a few percent (tests).
  * Input: a SYMMETRIC pattern (A = Aᵀ; self-loops ignored; values play no part, as in the reference).
- * rank_out_dev[old] = new; community_out_dev (may be NULL): top-level vertex of every vertex; stats_host (may be NULL):
- * {communities, passes, vertices retried, vertices left top-level for lack of table or pool room}. */
+ * rank_out_dev[old] = new; community_out_dev (may be NULL): top-level vertex of every vertex; stats_host (may be NULL,
+ * else 8 words): {communities, passes, vertices retried, vertices left top-level for lack of table or pool room, and
+ * four guard counters — pointer chain, child chain, full table, bad index}.  Every loop of the kernel is bounded by
+ * such a guard; all four are 0 in a sound run, and a non-zero one means an aggregation ran on broken state: the call
+ * then returns GCN_ERR_INTERNAL, prints one line and writes NO ordering (the counters are still reported). */
 int gcn_order_rabbit_device(const int32_t* rowptr_dev, const int32_t* col_dev, int32_t n, int32_t nnz,
                             int32_t* rank_out_dev, int32_t* community_out_dev, int64_t* stats_host, void* stream);
 

@@ -252,3 +252,61 @@ def test_prelaid_chain_exchanges_the_next_layers_input_directly(exchange):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok, _ in res), res
+
+
+class _RefusingPrelaidLocal(_OraclePrelaidLocal):
+    """an operator that does NOT offer the pre-laid layout (a rank whose block falls on the other side of a rule)"""
+
+    def prelaid_layout(self, k):
+        return None
+
+
+def _subgroup_worker(rank, nproc, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=nproc)
+    try:
+        members = [0, 2]
+        sub = dist.new_group(members)                        # (every process of the job calls new_group)
+        if rank not in members:
+            q.put((rank, True, "bystander"))
+            return
+        world, me = len(members), members.index(rank)
+        n, k = 17000, 8
+        rp, ci, va = sym_norm_graph(n, 1200000, seed=12)
+        deg = np.diff(rp).astype(np.float64)
+        u = torch.from_numpy(np.sqrt((deg ** -0.5 * deg ** -0.5).astype(np.float32)))
+        H = torch.from_numpy(np.random.default_rng(1).standard_normal((n, k)).astype(np.float32))
+        args = (torch.from_numpy(rp), torch.from_numpy(ci), torch.from_numpy(va), n, me, world)
+        # without the group the shard cannot find its peers: a 2-rank shard in a 3-rank job is refused, not mis-agreed
+        try:
+            RowShardedAdjacency(*args, _OraclePrelaidLocal, value_factor=u, plane_cols=8)
+            refused = False
+        except ValueError:
+            refused = True
+        # rank `members[1]`'s operator refuses the layout: BOTH ranks must fall back to the copying path together
+        local_cls = _RefusingPrelaidLocal if me == 1 else _OraclePrelaidLocal
+        shard = RowShardedAdjacency(*args, local_cls, value_factor=u, plane_cols=8, group=sub)
+        ok = refused and not shard.prelaid and shard.local.S is None      # downgraded, operator rebuilt without forced slices
+        a, b = shard.to_padded(H), shard.new_buffer(k, "cpu")
+        shard.layer(a, b)                                    # runs on the shard's own group
+        ref = oracle_spmm(rp, ci, va, H.numpy(), fp64=False)
+        ok = ok and np.array_equal(shard.from_padded(b).numpy(), ref)
+        q.put((rank, bool(ok), "member"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shard_on_a_subgroup_agrees_on_that_group_and_downgrades_together():
+    """the pre-laid agreement runs on the group the shard is given (not the default group), a shard whose
+    world differs from its group's size is refused, and a downgrade rebuilds the local operator"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_subgroup_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(3)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res), res

@@ -124,6 +124,7 @@ def test_rabbit_device_on_small_graphs_is_a_permutation_with_sound_communities()
                                                     return_communities=True, return_stats=True)
     rank, comm = rank.cpu().numpy(), comm.cpu().numpy()
     assert sorted(rank.tolist()) == list(range(24)) and stats["communities"] == 2
+    assert stats["guard_trips"] == [0, 0, 0, 0]          # every bounded loop ended by itself (a trip is an error: GCN_ERR_INTERNAL)
     assert len(set(comm[:12])) == 1 and len(set(comm[12:])) == 1 and comm[0] != comm[12]
     assert set(rank[:12]) in ({*range(12)}, {*range(12, 24)})                    # each clique one contiguous run
     # no edges at all, and edges among a few vertices only
@@ -181,6 +182,7 @@ def test_rabbit_device_matches_the_serial_rabbits_quality_at_a_fraction_of_its_t
         q_dev = reorder.modularity(rowptr, col, comm)
         assert q_dev >= 0.98 * q_host, (q_dev, q_host)
         assert 0.8 * planted <= stats["communities"] <= 1.3 * planted, stats
+        assert stats["guard_trips"] == [0, 0, 0, 0], stats
         print(f"rabbit n={n}: device {t_dev * 1e3:.1f} ms, host {t_host * 1e3:.1f} ms ({t_host / max(t_dev, 1e-9):.0f} x)")   # a figure, not a bar
         rp, ci, va, _ = reorder.apply_rank_device(rowptr, col, val, rank)
         adj = gcn_amd.CsrAdjacency(rp, ci, va, (n, n), symmetric=True, panels="auto")

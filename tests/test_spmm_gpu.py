@@ -496,7 +496,7 @@ def test_dropin_flexspmm_refuses_buffers_it_did_not_pack():
     assert "csr2tile packed nothing" in r.stderr                                # n_segs = 0
 
 
-def test_dropin_flexspmm_reads_its_launch_parameters_on_the_device():
+def test_dropin_flexspmm_reads_its_launch_parameters_on_the_device(capfd):
     """after the first call on a set of buffers flexspmm only enqueues kernels: the chunk and cut-row counts come
     from the header ON THE DEVICE (dropin_guard_kernel), so (i) a call can be captured into a HIP graph and replayed,
     and (ii) buffers whose header is overwritten later are not walked — C stays as handed over, nothing faults"""
@@ -540,6 +540,14 @@ def test_dropin_flexspmm_reads_its_launch_parameters_on_the_device():
     C.fill_(3.0)
     call()
     torch.cuda.synchronize()
+    assert bool((C == 3.0).all())
+    # ... and is not silent for good: the guard counts its refusals in host-mapped memory, the NEXT call
+    # reports them and forgets every remembered set of buffers — so this one has its header read again, on the host
+    capfd.readouterr()
+    call()
+    torch.cuda.synchronize()
+    err = capfd.readouterr().err
+    assert "refused on the device" in err and "not packed by this library's csr2tile" in err, err
     assert bool((C == 3.0).all())
 
 
