@@ -55,8 +55,8 @@ from gcn_amd.dist import PipelinedAggregation, RowShardedAdjacency   # noqa: E40
 HBM_PEAK = 8.0e12
 L2_PEAK = 34.5e12
 FABRIC_GATHER_CEILING = 8.6e12
-K_FEAT = {"reddit": 128, "products": 256, "rmat24": 512, "papers100m": 128}     # BASELINE.json configs 2-5
-ORDER = {"reddit": "none", "products": "rcm", "rmat24": "none", "papers100m": "none"}
+K_FEAT = {"reddit": 128, "products": 256, "rmat24": 512, "papers100m": 128, "reddit-dcsbm": 128}     # BASELINE.json configs 2-5 (+ the structured stand-in)
+ORDER = {"reddit": "none", "products": "rcm", "rmat24": "none", "papers100m": "none", "reddit-dcsbm": "none"}
 TOL = 1e-5
 FULL_CHECK_MAX_N = 3_000_000      # "fp64 ... on the full matrix for n <= 3 M, on a fixed random sample of 4 096 rows otherwise"
 CPU_SAMPLE_WORK = 1.6e10          # nnz x k of the CPU-baseline sample: about 10 s per torch.spmm on the box's host
@@ -149,6 +149,8 @@ def renumber(rowptr, col, val, order, dev, offline=0):
         rank, where = reorder.order_deg_device(rowptr, col, "total", True), "device"
     elif order == "rcm":
         rank, where = reorder.order_rcm_device(rowptr, col), "device"
+    elif order == "rabbit":
+        rank, where = reorder.order_rabbit_device(rowptr, col), "device (parallel Rabbit, rabbit_device.hip)"
     elif order == "gorder":
         pre = offline_gorder_rank(rowptr, col, offline) if offline else None
         if pre is not None:
@@ -174,9 +176,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--graph", default="reddit", choices=["reddit", "products", "rmat24", "papers100m"])
+    ap.add_argument("--graph", default="reddit", choices=["reddit", "products", "rmat24", "papers100m", "reddit-dcsbm"])
+    ap.add_argument("--mixing", type=float, default=0.35, help="--graph reddit-dcsbm: share of edge samples drawn across communities")
+    ap.add_argument("--communities", type=int, default=200, help="--graph reddit-dcsbm: planted communities (Zipf sizes)")
+    ap.add_argument("--slices", type=int, default=-1, help="single GPU: explicit column-slice count of the plan (-1 = automatic)")
     ap.add_argument("--k", type=int, default=0, help="feature width (0 = the width BASELINE.json names for the graph)")
-    ap.add_argument("--order", default="config", choices=["config", "none", "deg", "rcm", "gorder"],
+    ap.add_argument("--order", default="config", choices=["config", "none", "deg", "rcm", "gorder", "rabbit"],
                     help="single GPU: renumber the graph before the SpMM (config = what BASELINE.json names: RCM for "
                          "products, none otherwise)")
     ap.add_argument("--rmat-scale", type=int, default=24, help="--graph rmat24: log2 of the vertex count (24 = config 5)")
@@ -230,12 +235,13 @@ def main():
     k = args.k or K_FEAT[args.graph]
     order = ORDER[args.graph] if args.order == "config" else args.order
     papers = args.graph == "papers100m"
+    dcsbm = args.graph == "reddit-dcsbm"
     sim = args.sim_world if (world == 1 and args.sim_world > 1) else 0
     if papers and world == 1 and not sim:
         sim = 8                                              # one GPU: rank 0's share of the 8-way partition
     sharded = world > 1 or args.force_shard or sim > 1
     part_world, part_rank = (sim, 0) if sim else (world, rank)
-    if sharded and (order != "none" or args.graph in ("products", "rmat24")):
+    if sharded and (order != "none" or args.graph in ("products", "rmat24", "reddit-dcsbm")):
         sys.exit("bench.py: the row-sharded path runs the reddit / papers100m graphs un-renumbered")
     order_secs, order_where = 0.0, ""
 
@@ -250,6 +256,9 @@ def main():
                                    for t in graphgen.make_rmat(args.rmat_scale, device="cpu", seed=5))
         elif args.graph == "rmat24":
             rowptr, col, val, n = graphgen.make_rmat(args.rmat_scale, device=dev, seed=5)
+        elif dcsbm:
+            rowptr, col, val, n = graphgen.make_dcsbm(n=max(16, int(232965 * args.scale)), edges=int(57307946 * args.scale),
+                                                      communities=args.communities, mixing=args.mixing, device=dev, seed=11)
         else:
             rowptr, col, val, n = graphgen.make_graph(args.graph, device=dev, seed=1, scale=args.scale)
         if order != "none":
@@ -260,7 +269,8 @@ def main():
         H = graphgen.random_features(n, k, seed=2, device=dev)
         torch.cuda.synchronize(dev)
         t_plan = time.perf_counter()
-        adj = gcn_amd.CsrAdjacency(rowptr, col, val, (n, n), symmetric=True, chunk_nnz=args.chunk)
+        adj = gcn_amd.CsrAdjacency(rowptr, col, val, (n, n), symmetric=True, chunk_nnz=args.chunk,
+                                   slices="auto" if args.slices < 0 else args.slices)
         out = torch.empty((n, k), dtype=torch.float32, device=dev)
         adj.matmul_raw(H, out=out)                           # (the first call builds what the plan builds lazily for this width)
         torch.cuda.synchronize(dev)
@@ -442,16 +452,21 @@ def main():
     if rank == 0:
         flops = 2.0 * nnz * k if not sim else 2.0 * local_nnz * k
         ord_txt = {"none": "no reorder", "deg": "degree-descending order (order_deg)", "rcm": "RCM order (order_rcm)",
-                   "gorder": "Gorder (RCM then Gorder, window 3)"}[order]
+                   "gorder": "Gorder (RCM then Gorder, window 3)", "rabbit": "Rabbit order (parallel Rabbit on the device)"}[order]
         gname = (f"R-MAT scale {args.rmat_scale} (Graph500 a,b,c,d = .57,.19,.19,.05, edge factor 16, seed 5, labels permuted with seed 1005"
                  + (", CPU generator" if args.graph_device == "cpu" else "") + ")") if args.graph == "rmat24" \
-            else (f"{args.graph}-shaped R-MAT graph (gcn_amd.graphgen.make_graph: a,b,c,d = "
-                  + ",".join(f"{x:g}" for x in graphgen.SHAPES[args.graph]["abcd"]) + f", {graphgen.SHAPES[args.graph]['edges']} distinct "
-                  "undirected edges, seed 1, vertex labels randomly permuted with seed 1001, symmetrised, + I, "
-                  "D^-1/2 (A+I) D^-1/2; the milder skew than SURVEY §8(d)'s .57,.19,.19,.05 is deliberate, graphgen.py:18-21)")
+            else None
         if papers:
             gname = (f"papers100M-shaped R-MAT graph (graphgen.make_rmat_row_block: a,b,c,d = .57,.19,.19,.05, {PAPERS_SAMPLES} directed "
                      "samples, seed 4, labels permuted with seed 1004)")
+        elif dcsbm:
+            gname = (f"Reddit-sized degree-corrected planted-partition graph (graphgen.make_dcsbm: {args.communities} communities of "
+                     f"Zipf sizes, mixing {args.mixing}, power-law degrees gamma 2.5 capped near 20 k, seed 11, labels shuffled)")
+        elif gname is None:
+            gname = (f"{args.graph}-shaped R-MAT graph (gcn_amd.graphgen.make_graph: a,b,c,d = "
+                     + ",".join(f"{x:g}" for x in graphgen.SHAPES[args.graph]["abcd"]) + f", {graphgen.SHAPES[args.graph]['edges']} distinct "
+                     "undirected edges, seed 1, vertex labels randomly permuted with seed 1001, symmetrised, + I, "
+                     "D^-1/2 (A+I) D^-1/2; the milder skew than SURVEY §8(d)'s .57,.19,.19,.05 is deliberate, graphgen.py:18-21)")
         line = {
             "metric": "SpMM GFLOP/s + achieved HBM GB/s, Reddit feat=128, 1/2/4/8 MI355X",
             "value": round(flops * args.steps / elapsed / 1e9, 2),

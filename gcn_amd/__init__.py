@@ -12,4 +12,4 @@ from .spmm import CsrAdjacency, spmm, gather_rows, dropout_rows, install, uninst
 from . import reorder, dropin  # noqa: F401
 from .layers import GCN, GraphConvolution, GraphConvolution2  # noqa: F401
 
-__version__ = "0.2.0"
+__version__ = "0.3.0"

@@ -46,6 +46,7 @@ SIGNATURES = {
     "gcn_spmm_plan_enable_slicing": (ctypes.c_int, [_c_p, _c_p, _c_p, _c_p, _c_i32, _c_p]),
     "gcn_spmm_plan_num_slices": (_c_i32, [_c_p]),
     "gcn_spmm_plan_narrow_slices": (_c_i32, [_c_p, _c_i32]),
+    "gcn_spmm_plan_prepare_width": (_c_i32, [_c_p, _c_p, _c_p, _c_p, _c_i32, _c_p]),
     "gcn_spmm_plan_set_value_factors": (ctypes.c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p]),
     "gcn_spmm_plan_has_value_factors": (_c_i32, [_c_p]),
     "gcn_spmm_plan_enable_panels": (ctypes.c_int, [_c_p, _c_p, _c_p, _c_p, _c_i32, _c_p]),

@@ -25,7 +25,6 @@ using gcn::auto_chunk_nnz;
 using gcn::auto_slices;
 using gcn::auto_tile_cols;
 using gcn::cu_count_cached;
-using gcn::pad_b_enabled;
 using gcn::padded_ldb;
 using gcn::verbose;
 
@@ -147,7 +146,7 @@ long long dropin_phys(long long p) {                // group_phys of slicing.hip
 // pure function of (m, n, n_segs): does the pair use the group format, with how many slices, and where does
 // everything live in the caller's buffers?
 bool dropin_group(int m, int n, int n_segs, DropinGroup* g) {
-  if (!gcn::dropin_group_format_enabled() || m != n || n_segs <= 0) return false;
+  if (m != n || n_segs <= 0) return false;
   const long long nnz_lb = 9LL * n_segs, nnz_ub = 9LL * n_segs + 17;       // (n_segs may be nnz/9 - 1)
   const int S = auto_slices(m, n, nnz_lb, true);
   if (S <= 1) return false;
@@ -471,7 +470,7 @@ void flexspmm(int* seg_rowPtr, float* segNzCV, int* segVoMap, int* grouped_tailS
   const long long nnz_ub = 9LL * n_segs + 17;        // (n_segs is nnz/9 or one less)
   const int nchunks_ub = (int)((nnz_ub + T - 1) / T);
   // odd widths: computed at k' = k rounded up to 4 on row-padded copies, as in gcn_spmm_csr_f32_bias_relu
-  const bool odd = k > 16 && k % 4 != 0 && pad_b_enabled() &&
+  const bool odd = k > 16 && k % 4 != 0 &&
                    (long long)sizeof(float) * n * (((k + 3) / 4 * 4 + 31) / 32 * 32) <= (768LL << 20);
   const int kc = odd ? (k + 3) / 4 * 4 : k;                      // width the kernels compute at
   const int ldb = odd ? (kc + 31) / 32 * 32 : padded_ldb(n, k);  // row stride B is gathered with

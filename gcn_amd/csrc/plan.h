@@ -131,9 +131,6 @@ struct Panels {
   DevBuf<int> out_rowptr, out_col, out_chunk_row;   // the rest: plain CSR + its chunk plan
   DevBuf<float> out_val;
   int out_nnz = 0, out_T = 0, out_nchunks = 0;
-  int out_S = 0;                                    // column slices of the out-of-window part (0: unsliced)
-  DevBuf<int> out_vrowptr, out_vcol, out_vchunk_row;
-  DevBuf<float> out_vval;
   // dense panels on the matrix cores (spmm_panel_dense_mfma_kernel)
   int ndense = 0;
   DevBuf<int> dense_slot, dense_panel;              // [panels]: slot or -1; [ndense]: panel of every slot
@@ -163,11 +160,11 @@ struct gcn_spmm_plan {
   // Narrow widths (value-free plans whose slice count was automatic): the same matrix cut into FEWER, wider slices —
   // class 0: k <= 32, a row of the table is 128 bytes, so half as many slices fill an L2 and the partial rows (whose cost
   // goes with the slice count) halve.  (Class 1, 33..48 on 192-byte rows, was measured and is not built.)  Built at the
-  // first call of the class (api_spmm.cpp, maybe_build_alt); `use_alt`: the set the call in progress runs on (-1: the plan's own).
+  // first call of the class or by gcn_spmm_plan_prepare_width (plan_build.cpp, maybe_build_alt).  Which set a call runs on is
+  // decided per call and passed down as an argument (plan_policy.h, SliceSet) — never stored here.
   gcn::GroupStream group_alt[1];                    // (indexed by width class; one class so far)
   int alt_S[1] = {0};
   bool alt_tried[1] = {false};
-  int use_alt = -1;
   gcn::Factors factors;
   gcn::Panels panels;
 };
@@ -181,8 +178,6 @@ int auto_chunk_nnz(long long nnz, int cu);
 int auto_tile_cols(long long n, int k);
 int auto_slices(long long m, long long n, long long nnz, bool value_free = false);
 int padded_ldb(long long n, int k);
-bool pad_b_enabled();
-bool dropin_group_format_enabled();
 [[noreturn]] void die(const char* what, hipError_t e);
 bool verbose();
 // scratch plan of the stateless entry points (oneshot / cuspmm / flexspmm): one per (device, stream), never freed

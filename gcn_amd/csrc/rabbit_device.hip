@@ -406,9 +406,9 @@ hipError_t device_order_rabbit(const int* rowptr, const int* col, int n, int nnz
     // a vertex whose target was locked at the moment of the merge comes back in the next pass; a handful of passes
     // empties the list (what is left after 16 stays top-level)
     auto env_int = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
-    int max_passes = env_int("GCN_AMD_RABBIT_PASSES", 16);                  // development knobs
-    if (max_passes > kMaxPasses) max_passes = kMaxPasses;
-    const int retry_waves = env_int("GCN_AMD_RABBIT_RETRY_WAVES", nblocks);
+    const int max_passes = 16;
+    static_assert(16 <= kMaxPasses, "every pass owns a counter pair");
+    const int retry_waves = nblocks;
     // vertices in flight see each other's merges late: keep them a small share of the list (1 in 64 or fewer)
     auto waves_for = [&](unsigned cnt_) { long long w = (long long)cnt_ / 64; if (w < 8) w = 8; if (w > nblocks) w = nblocks; return (int)w; };
     Dev<unsigned> beat;

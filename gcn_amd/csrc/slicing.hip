@@ -309,12 +309,11 @@ hipError_t launch_slice_reduce(const float* Cv, float* C, const float* bias, int
   const uintptr_t al = (uintptr_t)Cv | (uintptr_t)C | (uintptr_t)bias | (uintptr_t)cuts.P;
   if (k % 4 == 0 && k <= 256 && (al & 15) == 0) {
     const long long steps = ((long long)m + 256 / k - 1) / (256 / k);   // wave steps of 256 / k rows (1 KiB when k divides 256)
-    static const int cap_env = [] { const char* e = getenv("GCN_AMD_REDUCE_BLOCKS"); return e ? atoi(e) : 0; }();   // development knob
-    const int cap = cap_env > 0 ? cap_env : 16384;
+    const int cap = 16384;
     const int nbw = (int)(steps / 4 + 1 < cap ? steps / 4 + 1 : cap);
     const bool off32 = (size_t)m * (size_t)k * 4 < (1ull << 32);   // a lane's byte offset inside a plane of partial rows
-    static const int lds_env = [] { const char* e = getenv("GCN_AMD_REDUCE_LDS"); return e ? atoi(e) : 0; }();   // development: LDS bytes per block = an occupancy limit
-#define GCN_RW(D, O) slice_reduce_wide_kernel<D, O><<<nbw, 256, (size_t)lds_env, st>>>(Cv, C, bias, relu, m, S, k, accumulate, rowscale, drop, guard, outscale, gap_w, cuts)
+    // (62 VGPRs: eight waves per SIMD, and the kernel wants them all — 344 / 357 / 374 / 399 us at 8 / 7 / 5 / 4, profiles/r03am_*)
+#define GCN_RW(D, O) slice_reduce_wide_kernel<D, O><<<nbw, 256, 0, st>>>(Cv, C, bias, relu, m, S, k, accumulate, rowscale, drop, guard, outscale, gap_w, cuts)
     if (drop.on()) { if (off32) GCN_RW(true, true); else GCN_RW(true, false); }
     else           { if (off32) GCN_RW(false, true); else GCN_RW(false, false); }
 #undef GCN_RW

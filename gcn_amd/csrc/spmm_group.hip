@@ -231,14 +231,9 @@ group_walk(const unsigned short* __restrict__ stream, const float* __restrict__ 
   }
 }
 
-template <int POLICY, bool BIG>
-__global__ void __launch_bounds__(256)
-spmm_group_kernel(const unsigned short* __restrict__ stream, const int2* __restrict__ chunk_meta,
-                  const float* __restrict__ Bp, float* __restrict__ Cv, float* __restrict__ P,
-                  int nchunks, int T, int k, int col_tile, int ldb, int stream_nt, int blocks_per_tile, const int* __restrict__ dyn) {
-  group_walk<POLICY, false, false, BIG>(stream, nullptr, chunk_meta, Bp, Cv, P, nchunks, T, k, col_tile, ldb, stream_nt, blocks_per_tile, dyn);
-}
-
+// (the value-free walk WITHOUT the LDS ring — every finished row stored by its own group at once — was the r02 kernel; with
+//  the ring 2.929 -> 2.874 ms, profiles/r02zt_*: only the ring variant is instantiated.  The weighted walk has none: it
+//  sits at 126 VGPRs already and the ring bought nothing there, 3.184 -> 3.176 ms.)
 template <int POLICY, bool BIG>
 __global__ void __launch_bounds__(256)
 spmm_group_ring_kernel(const unsigned short* __restrict__ stream, const int2* __restrict__ chunk_meta,
@@ -632,7 +627,7 @@ bool spmm_group_eligible(int k, int ldb, long long table_rows, const void* B, co
 bool spmm_group12_applies(const GroupArgs& a) {
   static const bool on = [] { const char* e = getenv("GCN_AMD_GROUP12"); return !e || e[0] != '0'; }();
   const int ldb = a.ldb > 0 ? a.ldb : a.k;
-  return on && a.narrow12 && !a.vals && a.ring && a.k > 32 && a.k <= 48 && a.k % 4 == 0 && !spmm_group_needs_big(a.table_rows, ldb);
+  return on && a.narrow12 && !a.vals && a.k > 32 && a.k <= 48 && a.k % 4 == 0 && !spmm_group_needs_big(a.table_rows, ldb);
 }
 
 // k <= 32, whole waves of eight chunks per XCD: the eight-engine kernels take the launch
@@ -648,35 +643,30 @@ hipError_t launch_group8_t(const GroupArgs& a, int ldb, hipStream_t s) {
   const int stream_nt8 = (size_t)a.nchunks * (size_t)a.T * (a.vals ? 6u : 2u) > ((size_t)64 << 20) ? 1 : 0;
   const int nb8 = 8 * ((per_xcd + 31) / 32);
   const int2* meta = reinterpret_cast<const int2*>(a.chunk_meta);
-  if (a.vals)      spmm_group8_weighted_kernel<BIG><<<dim3(nb8), dim3(256), 0, s>>>(a.stream, a.vals, meta, a.Bp, a.Cv, a.P, a.nchunks, a.T, a.k, ldb, stream_nt8, a.dyn);
-  else if (a.ring) spmm_group8_kernel<true, BIG><<<dim3(nb8), dim3(256), 0, s>>>(a.stream, meta, a.Bp, a.Cv, a.P, a.nchunks, a.T, a.k, ldb, stream_nt8, a.dyn);
-  else             spmm_group8_kernel<false, BIG><<<dim3(nb8), dim3(256), 0, s>>>(a.stream, meta, a.Bp, a.Cv, a.P, a.nchunks, a.T, a.k, ldb, stream_nt8, a.dyn);
+  if (a.vals) spmm_group8_weighted_kernel<BIG><<<dim3(nb8), dim3(256), 0, s>>>(a.stream, a.vals, meta, a.Bp, a.Cv, a.P, a.nchunks, a.T, a.k, ldb, stream_nt8, a.dyn);
+  else        spmm_group8_kernel<true, BIG><<<dim3(nb8), dim3(256), 0, s>>>(a.stream, meta, a.Bp, a.Cv, a.P, a.nchunks, a.T, a.k, ldb, stream_nt8, a.dyn);
   return hipGetLastError();
 }
 
-template <int POLICY, bool BIG>
-hipError_t launch_group_tp(const GroupArgs& a, int ldb, hipStream_t s) {
+// partial rows leave with non-temporal stores (POLICY 2): sc1 2.86 / 2.74 / 2.76 ms, plain 2.86 / 2.75 / 2.71, nt 2.82 / 2.66 /
+// 2.53 at 8 / 12 / 16 slices (profiles/r02z4_store_policy.log) — the only policy instantiated
+template <bool BIG>
+hipError_t launch_group_t(const GroupArgs& a, int ldb, hipStream_t s) {
   const int per_xcd = a.nchunks / 8;
   int nblocks = 8 * ((per_xcd + 15) / 16);
   const int tiles = (a.k + 63) / 64;
   // streams (2 or 6 bytes per entry) beyond what the L2s and a good part of the Infinity Cache hold are read non-temporally
   const int stream_nt = (size_t)a.nchunks * (size_t)a.T * (a.vals ? 6u : 2u) > ((size_t)64 << 20) ? 1 : 0;
-  // all tiles in ONE launch (merge_tiles): tile t+1 starts on the CUs that tile t's last blocks leave idle
-  const int tiles_per_launch = a.merge_tiles ? tiles : 1;
-  if ((long long)nblocks * tiles_per_launch >= (1LL << 31)) return hipErrorInvalidValue;
+  // all tiles in ONE launch: tile t+1 starts on the CUs that tile t's last blocks leave idle (k = 128 / 256: 2.89 / 5.70 ->
+  // 2.87 / 5.66 ms, profiles/r02zzb_merged_tile_launch.log)
+  if ((long long)nblocks * tiles >= (1LL << 31)) return hipErrorInvalidValue;
   const int blocks_per_tile = nblocks;
-  nblocks *= tiles_per_launch;
+  nblocks *= tiles;
   const int2* meta = reinterpret_cast<const int2*>(a.chunk_meta);
-  // development: dynamic LDS bytes per block = an occupancy limit (160 KiB per CU; the ring kernel holds 16 KiB itself)
-  static const size_t lds_env = [] { const char* e = getenv("GCN_AMD_GROUP_LDS"); return e ? (size_t)atoi(e) : (size_t)0; }();
-  for (int t = 0; t < tiles; t += tiles_per_launch) {
-    if (a.vals)
-      spmm_group_weighted_kernel<POLICY, BIG><<<dim3(nblocks), dim3(256), lds_env, s>>>(a.stream, a.vals, meta, a.Bp, a.Cv, a.P, a.nchunks, a.T, a.k, t, ldb, stream_nt, blocks_per_tile, a.dyn);
-    else if (a.ring)
-      spmm_group_ring_kernel<POLICY, BIG><<<dim3(nblocks), dim3(256), lds_env, s>>>(a.stream, meta, a.Bp, a.Cv, a.P, a.nchunks, a.T, a.k, t, ldb, stream_nt, blocks_per_tile, a.dyn);
-    else
-      spmm_group_kernel<POLICY, BIG><<<dim3(nblocks), dim3(256), lds_env, s>>>(a.stream, meta, a.Bp, a.Cv, a.P, a.nchunks, a.T, a.k, t, ldb, stream_nt, blocks_per_tile, a.dyn);
-  }
+  if (a.vals)
+    spmm_group_weighted_kernel<2, BIG><<<dim3(nblocks), dim3(256), 0, s>>>(a.stream, a.vals, meta, a.Bp, a.Cv, a.P, a.nchunks, a.T, a.k, 0, ldb, stream_nt, blocks_per_tile, a.dyn);
+  else
+    spmm_group_ring_kernel<2, BIG><<<dim3(nblocks), dim3(256), 0, s>>>(a.stream, meta, a.Bp, a.Cv, a.P, a.nchunks, a.T, a.k, 0, ldb, stream_nt, blocks_per_tile, a.dyn);
   return hipGetLastError();
 }
 
@@ -698,10 +688,7 @@ hipError_t launch_spmm_group(const GroupArgs& a, hipStream_t s) {
                                                          a.nchunks, a.T, a.k, ldb, stream_nt12, a.dyn);
     return hipGetLastError();
   }
-  if (big) return launch_group_tp<2, true>(a, ldb, s);               // (the store policy is a tuning knob: BIG keeps the default)
-  if (a.store_policy == 1) return launch_group_tp<1, false>(a, ldb, s);
-  if (a.store_policy == 2) return launch_group_tp<2, false>(a, ldb, s);
-  return launch_group_tp<0, false>(a, ldb, s);
+  return big ? launch_group_t<true>(a, ldb, s) : launch_group_t<false>(a, ldb, s);
 }
 
 }  // namespace gcn

@@ -109,11 +109,10 @@ struct GroupArgs {
   const int* dyn = nullptr;      // drop-in flexspmm: device words {buffers recognised, chunk count, cut rows}; nchunks is then an
                                  // upper bound that sizes the grid (dropin_guard_kernel, api_dropin.cpp)
   long long table_rows = 0;      // rows of Bp, S * (w + 1): decides 32-bit or 64-bit (BIG) slice-base addressing
-  int store_policy = 2;          // partial-row stores: 0 plain, 1 sc1 (write-through), 2 nt (streaming)
   int narrow8 = 1;               // k <= 32 on the eight-engine kernel (spmm_group8_kernel) when nchunks % 64 == 0
   int narrow12 = 1;              // 33 <= k <= 48, value-free: the five-engine kernel (spmm_group12_kernel)
-  int merge_tiles = 1;           // every 64-column tile in one launch (tile t+1 fills the CUs tile t's tail leaves idle)
-  int ring = 1;                  // value-free pass: finished rows leave through the LDS ring, four at a time (spmm_group_ring_kernel)
+  // (partial rows leave with non-temporal stores, finished rows of the value-free pass through the LDS ring, every
+  //  64-column tile in one launch: the alternatives were measured in round 2 and are no longer built)
 };
 bool spmm_group_eligible(int k, int ldb, long long table_rows, const void* B, const void* C, const void* P);
 bool spmm_group_needs_big(long long table_rows, int ldb);

@@ -467,9 +467,8 @@ int pick_vec(int k, int tile_cols, const void* B, const void* C, const void* P) 
 constexpr int kQuadMinRowLen = 48;
 
 static bool use_quad(const SpmmArgs& a) {
-  static const bool quad_on = [] { const char* v = getenv("GCN_AMD_QUAD"); return !v || v[0] != '0'; }();
-  static const int min_k = [] { const char* v = getenv("GCN_AMD_QUAD_MIN_K"); return v ? atoi(v) : 12; }();
-  if (!quad_on || a.gather_width == 1 || a.k < min_k || !spmm_quad_eligible(a)) return false;
+  constexpr int min_k = 12;               // (below: the narrow kernels' 4-byte-per-lane gathers, spmm_narrow.hip)
+  if (a.gather_width == 1 || a.k < min_k || !spmm_quad_eligible(a)) return false;
   // Short rows: every finished row costs the quad layout a cross-lane reduction (8-16 shuffles) where
   // the one-per-gather kernel just stores.  R-MAT, n = 1 M, k = 64 (profiles/r01f_lowdeg_probe.log), one-
   // vs four-per-gather: mean degree 4.9: 0.229 vs 0.508 ms; 8.8: 0.33 vs 0.56; 16: 0.54 vs 0.64;
@@ -502,28 +501,21 @@ hipError_t launch_spmm(const SpmmArgs& a, int cu_count, hipStream_t s) {
   // the empty rows first (the main kernels never write them), outside the timed interval of the main kernel
   if (a.empty_rows != 0 && (e = launch_fill_empty_rows(a.rowptr, a.C, a.bias, a.relu, a.accumulate, a.m, a.k, s)) != hipSuccess) return e;
   if (a.ev_start && (e = hipEventRecord(a.ev_start, s)) != hipSuccess) return e;
-  static const bool narrow_on = [] { const char* v = getenv("GCN_AMD_NARROW"); return !v || v[0] != '0'; }();
   if (a.valless && !use_quad(a)) return hipErrorInvalidValue;
   if (use_quad(a)) {
     // 16-byte-per-lane gathers, 4 (k > 16) or 16 (k <= 16) non-zeros per instruction (spmm_quad.hip)
     e = launch_spmm_quad(a, nblocks, epi, s);
-  } else if (a.k <= 16 && narrow_on && (a.ldb == 0 || a.ldb == a.k)) {
+  } else if (a.k <= 16 && (a.ldb == 0 || a.ldb == a.k)) {
     // k <= 16 without the alignment the quad kernel needs: several non-zeros per 4-byte-per-lane gather
     e = launch_spmm_narrow(a, nblocks, epi, s);
   } else switch (pick_vec(a.k, a.tile_cols, a.B, a.C, a.P)) {
     case 4:  e = launch_main<4, 4>(a, nblocks, epi, s); break;
     case 2:  e = launch_main<2, 8>(a, nblocks, epi, s); break;
-    default: {
-      // gathers in flight per wave for the 64-column tile (development knob GCN_AMD_U1;
-      // measured on the sliced Reddit-shaped case, whole SpMM: U = 4 / 8 / 16 / 32 ->
-      // 5.16 / 4.33 / 4.18 / 4.09 ms; 52 VGPRs at U = 32, still 8 waves per SIMD)
-      static const int u1 = [] { const char* v = getenv("GCN_AMD_U1"); return v ? atoi(v) : 32; }();
-      if (u1 == 16)     e = launch_main<1, 16>(a, nblocks, epi, s);
-      else if (u1 == 8) e = launch_main<1, 8>(a, nblocks, epi, s);
-      else if (u1 == 4) e = launch_main<1, 4>(a, nblocks, epi, s);
-      else              e = launch_main<1, 32>(a, nblocks, epi, s);
+    default:
+      // 32 gathers in flight per wave for the 64-column tile (measured on the sliced Reddit-shaped case, whole SpMM:
+      // U = 4 / 8 / 16 / 32 -> 5.16 / 4.33 / 4.18 / 4.09 ms; 52 VGPRs at U = 32, still 8 waves per SIMD)
+      e = launch_main<1, 32>(a, nblocks, epi, s);
       break;
-    }
   }
   if (e != hipSuccess) return e;
   if (a.ev_stop && (e = hipEventRecord(a.ev_stop, s)) != hipSuccess) return e;
@@ -543,8 +535,6 @@ hipError_t launch_spmm(const SpmmArgs& a, int cu_count, hipStream_t s) {
 void describe_main_kernel(const SpmmArgs& a, char* buf, size_t len) {
   const bool epi = (a.bias != nullptr) || a.relu;
   const char* e = epi ? "true" : "false";
-  static const bool narrow_on = [] { const char* v = getenv("GCN_AMD_NARROW"); return !v || v[0] != '0'; }();
-  static const int u1 = [] { const char* v = getenv("GCN_AMD_U1"); return v ? atoi(v) : 32; }();
   const bool buf32 = (unsigned long long)a.n * (unsigned long long)(a.ldb > 0 ? a.ldb : a.k) * 4ull < 0xFFFFFFF0ull;
   if (a.nchunks_grid == 0) { snprintf(buf, len, "gcn::spmm_empty_kernel"); return; }
   if (use_quad(a)) {
@@ -552,7 +542,7 @@ void describe_main_kernel(const SpmmArgs& a, char* buf, size_t len) {
              a.col16 ? "true" : "false");
     return;
   }
-  if (a.k <= 16 && narrow_on && (a.ldb == 0 || a.ldb == a.k)) {
+  if (a.k <= 16 && (a.ldb == 0 || a.ldb == a.k)) {
     if (a.k > 8 && buf32 && a.n < (1 << 24)) snprintf(buf, len, "gcn::spmm_narrow16_dpp_kernel<%s>", e);
     else {
       const int g = a.k <= 4 ? 4 : (a.k <= 8 ? 8 : 16);
@@ -563,8 +553,7 @@ void describe_main_kernel(const SpmmArgs& a, char* buf, size_t len) {
   const int vec = pick_vec(a.k, a.tile_cols, a.B, a.C, a.P);
   if (vec == 4) { snprintf(buf, len, "gcn::spmm_chunk_kernel<4, 4, %s, false>", e); return; }
   if (vec == 2) { snprintf(buf, len, "gcn::spmm_chunk_kernel<2, 8, %s, false>", e); return; }
-  const int u = (u1 == 16 || u1 == 8 || u1 == 4) ? u1 : 32;
-  snprintf(buf, len, "gcn::spmm_chunk_kernel<1, %d, %s, %s>", u, e, buf32 ? "true" : "false");
+  snprintf(buf, len, "gcn::spmm_chunk_kernel<1, 32, %s, %s>", e, buf32 ? "true" : "false");
 }
 
 // dst[r, 0:k] = src[r, 0:k], dst[r, k:ld] = 0: feature rows re-laid on whole 128-byte lines

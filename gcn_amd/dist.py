@@ -376,10 +376,8 @@ class PipelinedAggregation:
         # Staggered priorities: two chains of equal length started together stay in phase — both main kernels share
         # the chip and both tails (fix-up, slice reduction) end up exposed behind them, once per layer (rank share of an
         # 8-way partition: 2 x 166 us of main kernels, 390 us per layer).  With plane 0 ahead in priority its main
-        # kernel takes the chip first and its tail then runs beside plane 1's main kernel (GCN_AMD_PLANE_PRIORITY=0: equal).
-        import os
-        stagger = os.environ.get("GCN_AMD_PLANE_PRIORITY", "1") != "0"
-        self.streams = ([torch.cuda.Stream(dev, priority=(-1 if (stagger and p % 2 == 0) else 0)) for p in range(len(self.widths))]
+        # kernel takes the chip first and its tail then runs beside plane 1's main kernel (0.387 -> 0.384 ms at N = 8).
+        self.streams = ([torch.cuda.Stream(dev, priority=(-1 if p % 2 == 0 else 0)) for p in range(len(self.widths))]
                         if streams else None)
         self.locals = [shard.local] + [shard.another_local() if streams else shard.local for _ in self.widths[1:]]
 

@@ -159,6 +159,11 @@ int32_t gcn_spmm_plan_num_slices(const gcn_spmm_plan_t* plan);
  * many slices fill an L2, and the partial rows — whose cost goes with the slice count — halve (Reddit-shaped: 8
  * instead of 15). */
 int32_t gcn_spmm_plan_narrow_slices(const gcn_spmm_plan_t* plan, int32_t k);
+/* Build NOW whatever a k-wide call of this plan would build at its first use (the narrow slice set above: device
+ * allocations and a stream synchronisation), e.g. before a stream capture whose first k-wide call must only enqueue
+ * kernels.  The matrix arrays must be the ones the plan was created for.  Idempotent; GCN_OK also when nothing is to build. */
+int gcn_spmm_plan_prepare_width(gcn_spmm_plan_t* plan, const int32_t* rowptr_dev, const int32_t* col_dev,
+                                const float* val_dev, int32_t k, void* stream);
 
 /* Rank-1 values.  When every stored value is u_row[r] * u_col[c] — the GCN normalisation
  * D^-1/2 (A+I) D^-1/2 has u = D^-1/2 — the sliced main pass runs WITHOUT its value stream (5 % of the

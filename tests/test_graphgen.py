@@ -76,3 +76,35 @@ def test_rank_local_row_blocks_equal_slices_of_the_whole_graph():
             assert torch.equal(col, ci[e0:e1].long()) and torch.equal(val, va[e0:e1])
             rows = torch.repeat_interleave(torch.arange(lo, hi), (lrp[1:] - lrp[:-1]).long())
             assert float(((u[rows] * u[col] - val).abs() / val).max()) < 4e-7
+
+
+def test_dcsbm_generator_plants_communities_and_hits_the_requested_size():
+    """graphgen.make_dcsbm (the structured stand-in of round 4): exact edge count, symmetric normalised adjacency with
+    self-loops, skewed degrees, heterogeneous communities, a realised mixing near the one asked for, deterministic,
+    and labels that really are shuffled"""
+    import torch
+    from gcn_amd import graphgen
+    n, edges = 6000, 300000
+    rp, ci, va, n2, comm = graphgen.make_dcsbm(n=n, edges=edges, communities=12, mixing=0.3, max_degree=1500, seed=3,
+                                               return_communities=True)
+    assert n2 == n and int(ci.numel()) == 2 * edges + n and int(rp[-1]) == 2 * edges + n
+    deg = (rp[1:] - rp[:-1]).long()
+    rows = torch.repeat_interleave(torch.arange(n), deg)
+    A = torch.sparse_coo_tensor(torch.stack([rows, ci.long()]), va, (n, n)).to_dense()
+    assert torch.equal(A, A.t()) and bool((torch.diagonal(A) > 0).all())
+    u = deg.double().pow(-0.5)
+    assert torch.allclose(va.double(), u[rows] * u[ci.long()], rtol=1e-6)
+    assert int(deg.max()) > 5 * float(deg.float().mean())                # hubs
+    sizes = torch.bincount(comm)
+    assert sizes.numel() == 12 and int(sizes.max()) > 4 * int(sizes.min())
+    off = rows != ci.long()
+    cross = float((comm[rows[off]] != comm[ci.long()[off]]).float().mean())
+    assert 0.25 <= cross <= 0.45, cross
+    # labels shuffled: consecutive vertices are in the same community no more often than chance
+    same_next = float((comm[:-1] == comm[1:]).float().mean())
+    assert same_next < 2.0 * float((sizes.double() / n).pow(2).sum())
+    again = graphgen.make_dcsbm(n=n, edges=edges, communities=12, mixing=0.3, max_degree=1500, seed=3)
+    assert torch.equal(again[1], ci) and torch.equal(again[0], rp)
+    planted = graphgen.make_dcsbm(n=n, edges=edges, communities=12, mixing=0.3, max_degree=1500, seed=3, relabel=False,
+                                  return_communities=True)[4]
+    assert bool((planted[1:] >= planted[:-1]).all())                     # un-shuffled: community by community

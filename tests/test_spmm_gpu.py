@@ -855,7 +855,7 @@ def test_value_free_sliced_pass_for_normalised_adjacencies():
     val3 = (rng.random(len(val)) + 0.1).astype(np.float32)
     adj3 = _adj(rowptr, col, val3, n, n)
     assert adj3.main_kernel(128).startswith("gcn::spmm_group_weighted_kernel<")
-    if os.environ.get("GCN_AMD_GROUP8", "1") != "0" and int(os.environ.get("GCN_AMD_GROUP_MIN_K", "12")) <= 12:
+    if os.environ.get("GCN_AMD_GROUP8", "1") != "0":
         assert adj3.main_kernel(16).startswith("gcn::spmm_group8_weighted_kernel<")   # k <= 32: eight engines per wave
     for k in (64, 100, 41, 16, 20, 30):                  # 100, 41, 30: on the row-padded / odd-width copies
         Bk = rng.standard_normal((n, k)).astype(np.float32)
@@ -983,7 +983,7 @@ def test_narrow_widths_on_the_eight_engine_kernel(S):
     rng = np.random.default_rng(S)
     adj = _adj(rowptr, col, val, n, n, slices=S)
     assert adj.num_slices == S and adj.has_value_factors
-    g8_on = os.environ.get("GCN_AMD_GROUP8", "1") != "0" and int(os.environ.get("GCN_AMD_GROUP_MIN_K", "12")) <= 12
+    g8_on = os.environ.get("GCN_AMD_GROUP8", "1") != "0"            # (tools/knob_matrix.sh runs the suite with the knob off)
     for k in (12, 16, 20, 24, 28, 32, 17, 30, 31):
         assert not g8_on or adj.main_kernel(k).startswith("gcn::spmm_group8_kernel<"), (k, adj.main_kernel(k))
         B = rng.standard_normal((n, k)).astype(np.float32)
@@ -995,9 +995,8 @@ def test_narrow_widths_on_the_eight_engine_kernel(S):
         assert torch.equal(C, adj.matmul_raw(Bd))
         Ce = adj.matmul_raw(Bd, bias=torch.from_numpy(bias).to(_dev()), relu=True).cpu().numpy()
         assert rel_err(Ce, np.maximum(Cref + bias, 0)) <= TOL, k
-    ring = os.environ.get("GCN_AMD_GROUP_RING", "1") != "0"
-    assert adj.main_kernel(36) in ("gcn::spmm_group12_kernel", "gcn::spmm_group_ring_kernel<2, false>") or not ring   # (GCN_AMD_GROUP12=0: the latter)
-    assert adj.main_kernel(52).startswith("gcn::spmm_group_ring_kernel<" if ring else "gcn::spmm_group_kernel<")
+    assert adj.main_kernel(36) in ("gcn::spmm_group12_kernel", "gcn::spmm_group_ring_kernel<2, false>")   # (GCN_AMD_GROUP12=0: the latter)
+    assert adj.main_kernel(52).startswith("gcn::spmm_group_ring_kernel<")
     assert not adj.main_kernel(8).startswith("gcn::spmm_group")
 
 
@@ -1142,10 +1141,9 @@ def test_second_slice_set_for_narrow_widths(scale):
     C128 = adj.matmul_raw(B128)
     assert adj.narrow_slices == 0                                            # (no narrow call so far)
     env = os.environ.get
-    narrow_on = env("GCN_AMD_GROUP_NARROW_SLICES", "1") != "0"                # (development knobs select other paths: the
-    g8_on = env("GCN_AMD_GROUP8", "1") != "0" and int(env("GCN_AMD_GROUP_MIN_K", "12")) <= 12   #  numbers below are checked either way)
-    g12_on = env("GCN_AMD_GROUP12", "1") != "0" and env("GCN_AMD_GROUP_RING", "1") != "0"
-    expect = (8 if scale == 1.0 else 4) if narrow_on and int(env("GCN_AMD_GROUP_MIN_K", "12")) <= 12 else 0
+    g8_on = env("GCN_AMD_GROUP8", "1") != "0"          # (tools/knob_matrix.sh runs the suite with these two off: the
+    g12_on = env("GCN_AMD_GROUP12", "1") != "0"        #  numbers below are checked either way)
+    expect = 8 if scale == 1.0 else 4
     for k in (16, 32, 12, 30, 7):
         B = graphgen.random_features(n, k, seed=10 + k, device=d)
         C = adj.matmul_raw(B)

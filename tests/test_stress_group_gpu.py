@@ -82,7 +82,7 @@ def test_group8_kernel_random(seed):
                                (n, n), slices=S)
     assert adj.num_slices == S and adj.has_value_factors
     name = adj.main_kernel(k)
-    knobs_off = os.environ.get("GCN_AMD_GROUP8", "1") == "0" or int(os.environ.get("GCN_AMD_GROUP_MIN_K", "12")) > 12
+    knobs_off = os.environ.get("GCN_AMD_GROUP8", "1") == "0"
     if len(col) // n >= 48 and not knobs_off:                    # (below: the weighted pass, see valless_pays)
         assert name.startswith("gcn::spmm_group8_kernel<"), (name, k)
     assert not adj.main_kernel(8).startswith("gcn::spmm_group")
@@ -110,7 +110,7 @@ def test_group12_kernel_random(seed):
                                (n, n), slices=S)
     assert adj.num_slices == S and adj.has_value_factors
     name = adj.main_kernel(k)
-    knobs_off = os.environ.get("GCN_AMD_GROUP12", "1") == "0" or os.environ.get("GCN_AMD_GROUP_RING", "1") == "0"
+    knobs_off = os.environ.get("GCN_AMD_GROUP12", "1") == "0"
     if len(col) // n >= 48 and not knobs_off:                    # (below: the weighted pass, see valless_pays)
         assert name == "gcn::spmm_group12_kernel", (name, k)
     assert name.startswith("gcn::spmm_group"), (name, k)
@@ -148,10 +148,8 @@ def _big_child():
             err = rel_err(C.cpu().numpy(), oracle_spmm(rowptr, col, val, B))
             assert err <= TOL, (seed, n, S, k, name, err)
     want = {"gcn::spmm_group_ring_kernel", "gcn::spmm_group_weighted_kernel", "gcn::spmm_group8_kernel"}
-    if os.environ.get("GCN_AMD_GROUP8", "1") == "0" or int(os.environ.get("GCN_AMD_GROUP_MIN_K", "12")) > 12:
-        want.discard("gcn::spmm_group8_kernel")                 # (development knobs that keep narrow widths off the eight-engine kernel)
-    if os.environ.get("GCN_AMD_GROUP_RING", "1") == "0":
-        want = {w.replace("_ring", "") for w in want}
+    if os.environ.get("GCN_AMD_GROUP8", "1") == "0":
+        want.discard("gcn::spmm_group8_kernel")                 # (the switch that keeps narrow widths off the eight-engine kernel)
     assert want <= seen, seen
     print("big ok", sorted(seen))
 

@@ -3,7 +3,7 @@
 planted-partition graphs in a community order.  Per configuration: whole SpMM (k = 128) from
 torch events, and — under rocprofv3 --kernel-trace — the per-kernel split.
     python tools/panel_mfma_probe.py [n=240000] [order=truth|communities|rcm]
-Set GCN_AMD_PANEL_MFMA=0 for the LDS-only panels, GCN_AMD_PANEL_MFMA_DENSITY for the threshold."""
+(Round 2 compared against LDS-only panels through a knob that round 4 removed: dense tiles from 25 % window density.)"""
 import os
 import sys
 import torch
@@ -24,7 +24,7 @@ nnz = int(col.numel())
 H = graphgen.random_features(n, 128, seed=2, device=dev)
 out = torch.empty((n, 128), device=dev)
 ref = None
-print(f"# planted partition n={n} nnz={nnz} order={order} GCN_AMD_PANEL_MFMA={os.environ.get('GCN_AMD_PANEL_MFMA', '1')}")
+print(f"# planted partition n={n} nnz={nnz} order={order}")
 for name, kw in (("gather only, unsliced", dict(panels=0, slices=0)), ("gather only, auto slices", dict(panels=0, slices="auto")),
                  ("panels (auto)", dict(panels="auto", slices=0))):
     adj = gcn_amd.CsrAdjacency(rowptr, col, val, (n, n), symmetric=True, **kw)
