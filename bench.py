@@ -203,6 +203,8 @@ def main():
                          "instead of writing the next layer's pre-laid input in the epilogue")
     ap.add_argument("--no-plane-streams", action="store_true",
                     help="debug: N > 1 / --sim-world: all column planes on one stream (default: one stream per plane)")
+    ap.add_argument("--tail-stream", action="store_true",
+                    help="debug: N > 1 / --sim-world: the planes' slice reductions on one high-priority stream of their own")
     ap.add_argument("--sim-world", type=int, default=0,
                     help="debug: on ONE GPU, time rank 0's row block of a W-way partition (compute only, "
                          "no collective) — a rehearsal of the per-rank work at N = W, not a metric")
@@ -301,7 +303,8 @@ def main():
         if sim:
             shard.collective = False
         # column planes of 64: the exchange of one plane overlaps the SpMM of the next
-        pipe = PipelinedAggregation(shard, k, dev, plane_cols=64, streams=False if args.no_plane_streams else None)
+        pipe = PipelinedAggregation(shard, k, dev, plane_cols=64, streams=False if args.no_plane_streams else None,
+                                    tail_stream=args.tail_stream)
 
         def fill(p, buf):                 # features exist in the exchange layout only: every rank fills ITS rows,
             g = torch.Generator(device=dev)   # one exchange assembles the layer input

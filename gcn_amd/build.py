@@ -21,7 +21,7 @@ OBJDIR = os.path.join(LIBDIR, "obj")
 ARCH = "gfx950"
 DROPIN_NAMES = ["flexspmm.so", "cuspmm.so", "tile.so", "permutate.so", "renumber.so"]
 
-SOURCES = ["spmm_kernels.hip", "spmm_narrow.hip", "spmm_quad.hip", "spmm_group.hip", "spmm_panel.hip", "slicing.hip", "reorder_device.hip", "rabbit_device.hip", "plan_policy.cpp", "plan_build.cpp", "api_spmm.cpp", "api_reorder.cpp", "api_dropin.cpp", "reorder.cpp"]
+SOURCES = ["spmm_kernels.hip", "spmm_narrow.hip", "spmm_quad.hip", "spmm_group.hip", "spmm_panel.hip", "slicing.hip", "reorder_device.hip", "rabbit_device.hip", "exchange.hip", "plan_policy.cpp", "plan_build.cpp", "api_spmm.cpp", "api_reorder.cpp", "api_dropin.cpp", "reorder.cpp"]
 HEADERS = ["spmm_kernels.h", "plan.h", "plan_policy.h", "philox.h", "reorder.h", os.path.join(INCLUDE, "gcn_spmm.h")]
 
 

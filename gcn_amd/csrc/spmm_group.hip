@@ -58,7 +58,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // store; the trailing s_nop keeps the compiler's next instruction off the data registers until the store has
 // read them, cdna_hip_programming.md §5.7.)
 // GCN_ABLATE (development builds only, tools/ablate_group.sh: wrong results, exact costs): bit 0 no partial-row stores,
-// bit 1 no row-end handling, bit 2 no stream loads after the first run, bit 3 partial rows at a stride of 64 floats
+// bit 1 no row-end handling, bit 2 no stream loads after the first run, bit 3 partial rows at a stride of 64 floats;
+// weighted walk (r04): bit 4 the value stream read from its first 4 KiB only (cache-resident: its bytes without its
+// traffic), bit 5 no value broadcast (every lane multiplies by its OWN entry's value), bit 6 adds instead of FMAs
 #ifndef GCN_ABLATE
 #define GCN_ABLATE 0
 #endif
@@ -162,7 +164,7 @@ group_walk(const unsigned short* __restrict__ stream, const float* __restrict__ 
     if (j == 0 && blk + 4 < T / 16 && !(GCN_ABLATE & 4)) {      // the next run, a whole run ahead of its use
       const int nx = (blk / 4 + 1) * 16;
       eq_nx = stream_nt ? __builtin_nontemporal_load(sp + nx) : sp[nx];
-      if constexpr (VALS) vq_nx = stream_nt ? __builtin_nontemporal_load(vp + nx) : vp[nx];
+      if constexpr (VALS) vq_nx = (GCN_ABLATE & 16) ? vp[nx & 255] : (stream_nt ? __builtin_nontemporal_load(vp + nx) : vp[nx]);
     }
     const unsigned e = ((j & 2 ? eq.y : eq.x) >> (16 * (j & 1))) & 0xFFFFu;
     int vbits = 0;                                              // this lane's entry's value; step u takes lane u's
@@ -179,8 +181,11 @@ group_walk(const unsigned short* __restrict__ stream, const float* __restrict__ 
     const unsigned long long ends = (GCN_ABLATE & 2) ? 0ull : __ballot(fl != 0);   // bit g*16+u: entry u of group g ends a row
     if (ends == 0ull) {
 #define GCN_G_ADD(UU)                                                                               \
-      if constexpr (VALS) {                                                                         \
-        const float vu = __builtin_bit_cast(float, row_bcast<UU>(vbits));                           \
+      if constexpr (VALS && (GCN_ABLATE & 64) != 0) {                                               \
+        acc.x += b[UU].x; acc.y += b[UU].y; acc.z += b[UU].z; acc.w += b[UU].w;                     \
+        asm volatile("" : : "v"(vbits));                                                            \
+      } else if constexpr (VALS) {                                                                  \
+        const float vu = __builtin_bit_cast(float, (GCN_ABLATE & 32) ? vbits : row_bcast<UU>(vbits)); \
         acc.x = fmaf(vu, b[UU].x, acc.x); acc.y = fmaf(vu, b[UU].y, acc.y);                         \
         acc.z = fmaf(vu, b[UU].z, acc.z); acc.w = fmaf(vu, b[UU].w, acc.w);                         \
       } else { acc.x += b[UU].x; acc.y += b[UU].y; acc.z += b[UU].z; acc.w += b[UU].w; }

@@ -356,7 +356,7 @@ class PipelinedAggregation:
     is also the kernel's preferred column tile when n·256 B fits the Infinity Cache.
     """
 
-    def __init__(self, shard, k, device, plane_cols=64, group=None, streams=None):
+    def __init__(self, shard, k, device, plane_cols=64, group=None, streams=None, tail_stream=False):
         self.shard, self.k, self.group = shard, int(k), group
         self.widths = [min(plane_cols, k - c) for c in range(0, k, plane_cols)]
         if shard.prelaid and any(w != plane_cols for w in self.widths):
@@ -377,9 +377,17 @@ class PipelinedAggregation:
         # the chip and both tails (fix-up, slice reduction) end up exposed behind them, once per layer (rank share of an
         # 8-way partition: 2 x 166 us of main kernels, 390 us per layer).  With plane 0 ahead in priority its main
         # kernel takes the chip first and its tail then runs beside plane 1's main kernel (0.387 -> 0.384 ms at N = 8).
-        self.streams = ([torch.cuda.Stream(dev, priority=(-1 if p % 2 == 0 else 0)) for p in range(len(self.widths))]
+        # tail_stream (r04): the planes' fix-up / slice-reduction passes on ONE high-priority stream of their own
+        # (CsrAdjacency.set_tail_stream), the planes' own streams at equal priority: a plane's tail is then dispatched ahead
+        # of everything else the moment its main kernel ends, beside the other plane's main kernel.
+        self.tail = torch.cuda.Stream(dev, priority=-1) if (streams and tail_stream) else None
+        self.streams = ([torch.cuda.Stream(dev, priority=(-1 if (p % 2 == 0 and self.tail is None) else 0)) for p in range(len(self.widths))]
                         if streams else None)
         self.locals = [shard.local] + [shard.another_local() if streams else shard.local for _ in self.widths[1:]]
+        if self.tail is not None:
+            for loc in {id(l): l for l in self.locals}.values():
+                if hasattr(loc, "set_tail_stream"):
+                    loc.set_tail_stream(self.tail)
 
     def set_local_option(self, name, *args):
         """apply a CsrAdjacency setter (set_blocks_per_cu, set_gather_width, ...) to every plane's operator"""

@@ -129,6 +129,14 @@ int gcn_spmm_plan_set_blocks_per_cu(gcn_spmm_plan_t* plan, int32_t blocks);
  * four-per-gather kernel wherever its layout applies, whatever the row length.  Any other value:
  * GCN_ERR_INVALID_ARG. */
 int gcn_spmm_plan_set_gather_width(gcn_spmm_plan_t* plan, int32_t nz_per_gather);
+/* The passes BEHIND the main kernel of a column-sliced SpMM (fix-up, slice reduction with the epilogue) on a stream of
+ * their own: main kernel on the call's stream -> event -> tail on `tail_stream` -> event -> the call's stream waits, so
+ * the call keeps its meaning (everything enqueued behind it on its stream sees the finished C).  For two plans that work
+ * side by side on two streams (the 64-column planes of the multi-GPU path): given a high-priority tail stream, a plan's
+ * short bandwidth-bound tail runs beside the OTHER plan's main kernel instead of queueing behind it.  NULL = off
+ * (default).  The stream must outlive the plan's calls; unsliced plans ignore it.  No reference counterpart
+ * (flexspmm.cu:512 launches one kernel on the legacy stream). */
+int gcn_spmm_plan_set_tail_stream(gcn_spmm_plan_t* plan, void* tail_stream);
 /* number of main-kernel launches (column passes) one k-wide SpMM issues with the current tile */
 int32_t gcn_spmm_plan_num_passes(const gcn_spmm_plan_t* plan, int32_t k);
 /* name (as rocprofv3 --kernel-trace prints it, without the argument list) of the main kernel a
@@ -309,6 +317,25 @@ int gcn_csr_apply_rank_device(const int32_t* rowptr_dev, const int32_t* col_dev,
  * then returns GCN_ERR_INTERNAL, prints one line and writes NO ordering (the counters are still reported). */
 int gcn_order_rabbit_device(const int32_t* rowptr_dev, const int32_t* col_dev, int32_t n, int32_t nnz,
                             int32_t* rank_out_dev, int32_t* community_out_dev, int64_t* stats_host, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* (1e) the "push" form of the multi-GPU layer exchange (gcn_amd/dist.py,      */
+/*      exchange="push"; csrc/exchange.hip).  The reference is single-GPU      */
+/*      (device 0 hard-coded, flexspmm.cu:507): no counterpart.  Every rank    */
+/*      maps its peers' exchange buffers once (IPC handles), writes its shard  */
+/*      of a layer output straight into them with the runtime's copy path      */
+/*      (no compute units), raises one flag per peer and layer behind the      */
+/*      data, and waits for its own flags with one wave.                       */
+/* ------------------------------------------------------------------------- */
+/* dst_peer[0:bytes] = src[0:bytes]; dst_peer is a pointer into a peer's buffer mapped into this process; asynchronous */
+int gcn_exchange_push(void* dst_peer, const void* src, size_t bytes, void* stream);
+/* *flag_peer = *value_dev (4 bytes), enqueued behind the pushes on the same stream: "my shard has landed" */
+int gcn_exchange_signal(int32_t* flag_peer, const int32_t* value_dev, void* stream);
+/* Enqueue ONE wave that returns when flags_dev[i] == value for every i < count (<= 64) except i == skip (-1: none).
+ * Bounded: after timeout_seconds a lane gives up and writes 1 + (the flag it waited for) to *status_dev (0 otherwise
+ * untouched) — the stream goes on, the caller checks the status word at its next synchronisation point. */
+int gcn_exchange_wait(const int32_t* flags_dev, int32_t count, int32_t skip, int32_t value, int32_t* status_dev,
+                      double timeout_seconds, void* stream);
 
 /* ------------------------------------------------------------------------- */
 /* (2) DROP-IN symbols — identical names and argument lists to the reference.  */
