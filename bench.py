@@ -189,8 +189,9 @@ def main():
                     help="--graph rmat24: generate the graph with the CPU generators (the same integers on every machine; a "
                          "Gorder rank computed off-line by tools/gorder_rmat24.py is then loaded instead of recomputed)")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the graph (debug only; invalidates the metric)")
-    ap.add_argument("--exchange", default="all_gather", choices=["all_gather", "direct"],
-                    help="N > 1: one RCCL all-gather per plane and layer, or a grouped send/recv to every peer")
+    ap.add_argument("--exchange", default="all_gather", choices=["all_gather", "direct", "push"],
+                    help="N > 1: one RCCL all-gather per plane and layer, a grouped send/recv to every peer, or shards pushed "
+                         "into the peers' IPC-mapped buffers by the copy engines (no collective kernel)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-shard", action="store_true",
                     help="debug: run the row-sharded pipelined path even with one rank (no collective)")
@@ -203,8 +204,6 @@ def main():
                          "instead of writing the next layer's pre-laid input in the epilogue")
     ap.add_argument("--no-plane-streams", action="store_true",
                     help="debug: N > 1 / --sim-world: all column planes on one stream (default: one stream per plane)")
-    ap.add_argument("--tail-stream", action="store_true",
-                    help="debug: N > 1 / --sim-world: the planes' slice reductions on one high-priority stream of their own")
     ap.add_argument("--sim-world", type=int, default=0,
                     help="debug: on ONE GPU, time rank 0's row block of a W-way partition (compute only, "
                          "no collective) — a rehearsal of the per-rank work at N = W, not a metric")
@@ -303,8 +302,7 @@ def main():
         if sim:
             shard.collective = False
         # column planes of 64: the exchange of one plane overlaps the SpMM of the next
-        pipe = PipelinedAggregation(shard, k, dev, plane_cols=64, streams=False if args.no_plane_streams else None,
-                                    tail_stream=args.tail_stream)
+        pipe = PipelinedAggregation(shard, k, dev, plane_cols=64, streams=False if args.no_plane_streams else None)
 
         def fill(p, buf):                 # features exist in the exchange layout only: every rank fills ITS rows,
             g = torch.Generator(device=dev)   # one exchange assembles the layer input
@@ -359,6 +357,7 @@ def main():
     elapsed = time.perf_counter() - t0
     kernel_ms = local_adj.profile_end()
     if sharded:
+        shard.check_exchange()                            # (push form: did a wait for a peer's flag give up?)
         # The check of the sharded path needs a layer's INPUT beside its output, i.e. a copy of the exchange buffers — tens
         # of GB for the papers100M-shaped graph, whose allocation alone took 1.6 s inside the timed loop when it was made
         # there.  So: the timed layers run undisturbed, and ONE more layer of the same pipeline, right behind them and

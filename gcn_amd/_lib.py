@@ -41,7 +41,10 @@ SIGNATURES = {
     "gcn_spmm_plan_set_tile_cols": (ctypes.c_int, [_c_p, _c_i32]),
     "gcn_spmm_plan_set_blocks_per_cu": (ctypes.c_int, [_c_p, _c_i32]),
     "gcn_spmm_plan_set_gather_width": (ctypes.c_int, [_c_p, _c_i32]),
-    "gcn_spmm_plan_set_tail_stream": (ctypes.c_int, [_c_p, _c_p]),
+    "gcn_exchange_flags_create": (ctypes.c_int, [_c_i32, _c_p, _c_p]),
+    "gcn_exchange_flags_open": (ctypes.c_int, [_c_p, _c_p]),
+    "gcn_exchange_flags_close": (ctypes.c_int, [_c_p]),
+    "gcn_exchange_flags_destroy": (ctypes.c_int, [_c_p]),
     "gcn_exchange_push": (ctypes.c_int, [_c_p, _c_p, ctypes.c_size_t, _c_p]),
     "gcn_exchange_signal": (ctypes.c_int, [_c_p, _c_p, _c_p]),
     "gcn_exchange_wait": (ctypes.c_int, [_c_p, _c_i32, _c_i32, _c_i32, _c_p, ctypes.c_double, _c_p]),

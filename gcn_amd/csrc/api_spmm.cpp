@@ -139,22 +139,15 @@ int spmm_impl(gcn_spmm_plan* p, const SliceSet& ss, const int32_t* rowptr, const
     if (ev0 && hipEventRecord(ev0, st) != hipSuccess) return GCN_ERR_HIP;
     if (launch_spmm_group(ga, st) != hipSuccess) return GCN_ERR_HIP;
     if (ev1 && hipEventRecord(ev1, st) != hipSuccess) return GCN_ERR_HIP;
-    // the passes behind the main kernel: on the call's stream, or on the plan's tail stream between two events
-    hipStream_t ts = st;
-    if (p->tail.on()) {
-      ts = p->tail.s;
-      if (hipEventRecord(p->tail.main_done, st) != hipSuccess || hipStreamWaitEvent(ts, p->tail.main_done, 0) != hipSuccess) return GCN_ERR_HIP;
-    }
     // rows cut by chunk ends: their later pieces are added by the reduction itself (cut lists per output row), or —
     // GCN_AMD_GROUP_FUSED_FIXUP=0, or a plan without the lists — by a pass of their own in front of it
+    // (Both passes on a high-priority stream of their own, and the main kernels of two plans taking turns, were built and
+    //  measured for the two planes of the multi-GPU layer in r04: 0.417 / 0.450 ms against 0.377 — DESIGN §6; removed again.)
     CutLists cuts;
     if (group_fused_fixup() && G.cutptr) { cuts.ptr = G.cutptr; cuts.chunk = G.cutchunk; cuts.P = p->ws; }
-    else if (launch_group_fixup(G.fix, G.nfix, p->ws, p->cv, k, ts) != hipSuccess) return GCN_ERR_HIP;
-    if (launch_slice_reduce(p->cv, C, bias, relu, p->m, S_run, k, ts, 0, weighted ? nullptr : p->factors.u_row.get(),
-                            epi.drop, nullptr, epi.outscale, epi.gap_w, cuts) != hipSuccess) return GCN_ERR_HIP;
-    if (p->tail.on() &&                                // whatever follows the call on its stream sees the finished result
-        (hipEventRecord(p->tail.tail_done, ts) != hipSuccess || hipStreamWaitEvent(st, p->tail.tail_done, 0) != hipSuccess)) return GCN_ERR_HIP;
-    return GCN_OK;
+    else if (launch_group_fixup(G.fix, G.nfix, p->ws, p->cv, k, st) != hipSuccess) return GCN_ERR_HIP;
+    return launch_slice_reduce(p->cv, C, bias, relu, p->m, S_run, k, st, 0, weighted ? nullptr : p->factors.u_row.get(),
+                               epi.drop, nullptr, epi.outscale, epi.gap_w, cuts) == hipSuccess ? GCN_OK : GCN_ERR_HIP;
   }
   a.rowptr = sl.vrowptr; a.col = sl.vcol; a.val = sl.vval; a.chunk_row = sl.vchunk_row;
   a.C = p->cv; a.m = sl.S * p->m; a.bias = nullptr; a.relu = 0;
@@ -235,16 +228,6 @@ int gcn_spmm_plan_prepare_width(gcn_spmm_plan_t* p, const int32_t* rowptr, const
   int ld_call = odd ? ((k + 3) / 4 * 4 + 31) / 32 * 32 : padded_ldb(p->n, k);
   bool relay48 = false;
   (void)pick_slice_set(p, odd ? (k + 3) / 4 * 4 : k, &ld_call, &relay48, /*build=*/true, rowptr, col, val, (hipStream_t)stream);
-  return GCN_OK;
-}
-
-int gcn_spmm_plan_set_tail_stream(gcn_spmm_plan_t* p, void* tail_stream) {
-  if (!p) return GCN_ERR_INVALID_ARG;
-  p->tail.clear();
-  if (!tail_stream) return GCN_OK;
-  if (hipEventCreateWithFlags(&p->tail.main_done, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&p->tail.tail_done, hipEventDisableTiming) != hipSuccess) { p->tail.clear(); return GCN_ERR_HIP; }
-  p->tail.s = (hipStream_t)tail_stream;
   return GCN_OK;
 }
 

@@ -35,6 +35,41 @@ wait_flags_kernel(const int* __restrict__ flags, int count, int skip, int value,
 
 extern "C" {
 
+// The flags live in FINE-GRAINED device memory (coherent at system scope: a peer's copy engine writes them, this GPU's
+// wave polls them — ordinary hipMalloc memory may sit stale in this GPU's L2) and travel between processes as raw
+// 64-byte IPC handles.
+int gcn_exchange_flags_create(int32_t count, int32_t** flags_dev_out, void* ipc_handle_out_64) {
+  if (count <= 0 || count > 64 || !flags_dev_out || !ipc_handle_out_64) return GCN_ERR_INVALID_ARG;
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "the ABI hands the IPC handle over as 64 raw bytes");
+  void* p = nullptr;
+  if (hipExtMallocWithFlags(&p, sizeof(int32_t) * 64, hipDeviceMallocFinegrained) != hipSuccess) return GCN_ERR_ALLOC;
+  hipIpcMemHandle_t h;
+  if (hipMemset(p, 0, sizeof(int32_t) * 64) != hipSuccess || hipIpcGetMemHandle(&h, p) != hipSuccess) { (void)hipFree(p); return GCN_ERR_HIP; }
+  __builtin_memcpy(ipc_handle_out_64, &h, 64);
+  *flags_dev_out = (int32_t*)p;
+  return GCN_OK;
+}
+
+int gcn_exchange_flags_open(const void* ipc_handle_64, int32_t** flags_peer_out) {
+  if (!ipc_handle_64 || !flags_peer_out) return GCN_ERR_INVALID_ARG;
+  hipIpcMemHandle_t h;
+  __builtin_memcpy(&h, ipc_handle_64, 64);
+  void* p = nullptr;
+  if (hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) return GCN_ERR_HIP;
+  *flags_peer_out = (int32_t*)p;
+  return GCN_OK;
+}
+
+int gcn_exchange_flags_close(int32_t* flags_peer) {
+  if (!flags_peer) return GCN_OK;
+  return hipIpcCloseMemHandle(flags_peer) == hipSuccess ? GCN_OK : GCN_ERR_HIP;
+}
+
+int gcn_exchange_flags_destroy(int32_t* flags_dev) {
+  if (!flags_dev) return GCN_OK;
+  return hipFree(flags_dev) == hipSuccess ? GCN_OK : GCN_ERR_HIP;
+}
+
 int gcn_exchange_push(void* dst_peer, const void* src, size_t bytes, void* stream) {
   if (bytes == 0) return GCN_OK;
   if (!dst_peer || !src) return GCN_ERR_INVALID_ARG;

@@ -85,25 +85,6 @@ class EventPairs {
   int cap_ = 0, n_ = 0;
 };
 
-// The passes BEHIND the main kernel of a sliced SpMM (fix-up, slice reduction) on a stream of their own
-// (gcn_spmm_plan_set_tail_stream): main kernel on the call's stream, event, tail on `s`, event, the call's stream waits.
-// What it is for: two plans working side by side on two streams (the column planes of the multi-GPU path) whose short,
-// bandwidth-bound tails should run at high priority beside the OTHER plan's main kernel instead of queueing behind it.
-struct TailStream {
-  hipStream_t s = nullptr;
-  hipEvent_t main_done = nullptr, tail_done = nullptr;
-  TailStream() = default;
-  TailStream(const TailStream&) = delete;
-  TailStream& operator=(const TailStream&) = delete;
-  ~TailStream() { clear(); }
-  void clear() {
-    if (main_done) (void)hipEventDestroy(main_done);
-    if (tail_done) (void)hipEventDestroy(tail_done);
-    main_done = tail_done = nullptr; s = nullptr;
-  }
-  bool on() const { return s != nullptr; }
-};
-
 // XCD-aware column slicing (slicing.hip): slice-major copy of the matrix with S*m virtual rows
 struct Slicing {
   int S = 0;                                        // 0 = off
@@ -169,7 +150,6 @@ struct gcn_spmm_plan {
   gcn::DevBuf<float> cpad;                          // result with k rounded up to a multiple of 4 (k % 4 != 0), grow-only
   gcn::DevBuf<int> dyn;                             // drop-in flexspmm: {recognised, chunks, cut rows, 0} of the current call (device)
   gcn::EventPairs prof;
-  gcn::TailStream tail;                             // off unless gcn_spmm_plan_set_tail_stream was called
   int tile_cols = 0;                                // 0 = auto
   int gather_width = 0;                             // non-zeros per gather instruction of the 64-column kernel: 0 auto, 1, 4
   int blocks_per_cu = 32;                           // grid size: blocks of 4 waves per CU (oversubscribed on purpose)

@@ -60,7 +60,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // GCN_ABLATE (development builds only, tools/ablate_group.sh: wrong results, exact costs): bit 0 no partial-row stores,
 // bit 1 no row-end handling, bit 2 no stream loads after the first run, bit 3 partial rows at a stride of 64 floats;
 // weighted walk (r04): bit 4 the value stream read from its first 4 KiB only (cache-resident: its bytes without its
-// traffic), bit 5 no value broadcast (every lane multiplies by its OWN entry's value), bit 6 adds instead of FMAs
+// traffic), bit 5 no value broadcast (every lane multiplies by its OWN entry's value), bit 6 adds instead of FMAs,
+// bit 7 the value-free walk WITHOUT the LDS ring, bit 8 the weighted walk WITH it (these two give right results)
 #ifndef GCN_ABLATE
 #define GCN_ABLATE 0
 #endif
@@ -244,7 +245,7 @@ __global__ void __launch_bounds__(256)
 spmm_group_ring_kernel(const unsigned short* __restrict__ stream, const int2* __restrict__ chunk_meta,
                        const float* __restrict__ Bp, float* __restrict__ Cv, float* __restrict__ P,
                        int nchunks, int T, int k, int col_tile, int ldb, int stream_nt, int blocks_per_tile, const int* __restrict__ dyn) {
-  group_walk<POLICY, false, true, BIG>(stream, nullptr, chunk_meta, Bp, Cv, P, nchunks, T, k, col_tile, ldb, stream_nt, blocks_per_tile, dyn);
+  group_walk<POLICY, false, (GCN_ABLATE & 128) == 0, BIG>(stream, nullptr, chunk_meta, Bp, Cv, P, nchunks, T, k, col_tile, ldb, stream_nt, blocks_per_tile, dyn);
 }
 
 // the same walk for matrices whose values do not factor: one fp32 value per entry beside the 16-bit stream,
@@ -256,7 +257,7 @@ spmm_group_weighted_kernel(const unsigned short* __restrict__ stream, const floa
                            const int2* __restrict__ chunk_meta, const float* __restrict__ Bp, float* __restrict__ Cv,
                            float* __restrict__ P, int nchunks, int T, int k, int col_tile, int ldb, int stream_nt, int blocks_per_tile,
                            const int* __restrict__ dyn) {
-  group_walk<POLICY, true, false, BIG>(stream, vals, chunk_meta, Bp, Cv, P, nchunks, T, k, col_tile, ldb, stream_nt, blocks_per_tile, dyn);
+  group_walk<POLICY, true, (GCN_ABLATE & 256) != 0, BIG>(stream, vals, chunk_meta, Bp, Cv, P, nchunks, T, k, col_tile, ldb, stream_nt, blocks_per_tile, dyn);
 }
 
 // ------------------------------------------------------------------------------------------------------------

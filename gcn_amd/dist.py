@@ -30,9 +30,15 @@ nccl, the list form on gloo; chosen once from the backend, never by catching an 
 failure must not make one rank issue a different collective than its peers); "direct" — every rank sends
 its shard to each peer and receives theirs in ONE grouped batch of point-to-point operations
 (`batch_isend_irecv`): on MI355X every GPU pair has its own xGMI link, so each shard crosses exactly one
-link once, where a ring all-gather forwards every shard over world-1 hops.  Both forms fill
-the same buffer with the same bytes.
+link once, where a ring all-gather forwards every shard over world-1 hops; "push" (r04) — no collective
+library at all on the data path: every rank maps its peers' exchange buffers ONCE (IPC handles, exchanged through the
+process group's object all-gather), then per layer writes its shard straight into every peer's buffer with the runtime's
+copy path (hipMemcpyAsync between devices: the SDMA engines, no compute units), raises one flag per peer behind the data,
+and one wave waits for its own world-1 flags before the next layer reads the buffer (csrc/exchange.hip) — so nothing
+competes for the CUs with the two oversubscribed SpMM main kernels of a layer.  All forms fill the same buffer with the
+same bytes.  None has been measured on multi-GPU hardware by this build.
 """
+import ctypes
 import os
 
 import numpy as np
@@ -102,8 +108,9 @@ class RowShardedAdjacency:
 
     def _setup(self, local_rowptr, gcol, val, bounds, rank, world, make_local, value_factor, total_nnz, exchange,
                prelaid="auto", plane_cols=64, group=None):
-        if exchange not in ("all_gather", "direct"):
-            raise ValueError("exchange must be 'all_gather' or 'direct'")
+        if exchange not in ("all_gather", "direct", "push"):
+            raise ValueError("exchange must be 'all_gather', 'direct' or 'push'")
+        self._push = {}            # exchange="push": data_ptr of a registered buffer -> _PushPeers
         self.rank, self.world, self.exchange, self.group = int(rank), int(world), exchange, group
         self.bounds = np.asarray(bounds, dtype=np.int64)
         if len(self.bounds) != self.world + 1 or self.bounds[0] != 0 or np.any(np.diff(self.bounds) < 0):
@@ -245,9 +252,36 @@ class RowShardedAdjacency:
             return "none"
         if self.exchange == "direct":
             return "batch_isend_irecv (direct exchange, one shard per peer link)"
+        if self.exchange == "push":
+            return "push (peer buffers mapped through IPC, hipMemcpyAsync per peer + one flag per layer, no collective kernel)"
         return "all_gather_into_tensor" if dist.get_backend(group) == "nccl" else "all_gather (list form)"
 
+    def register_exchange_buffers(self, buffers, group=None):
+        """exchange="push": map every peer's counterpart of these exchange buffers into this process, once.  Every rank
+        calls it with the same number of buffers of the same shapes, in the same order (a collective: IPC handles travel
+        through all_gather_object).  The buffers must stay alive and keep their storage while the shard is used."""
+        if self.exchange != "push" or self.world == 1 or not self.collective:
+            return
+        group = group if group is not None else self.group
+        for buf in buffers:
+            self._push[buf.data_ptr()] = _PushPeers(self, buf, group)
+
+    def check_exchange(self):
+        """exchange="push": did a wait give up (a peer that never signalled)?  Synchronises; raises GcnAmdError."""
+        for reg in self._push.values():
+            torch.cuda.synchronize(reg.status.device)
+            bad = int(reg.status.item())
+            if bad:
+                raise _lib.GcnAmdError(f"push exchange: rank {self.rank} gave up waiting for the flag of rank {bad - 1}")
+
     def _exchange(self, out_padded, slot, group, async_op):
+        if self.exchange == "push":
+            reg = self._push.get(out_padded.data_ptr())
+            if reg is None:
+                raise _lib.GcnAmdError("exchange='push': the buffer was not registered (register_exchange_buffers; "
+                                       "PipelinedAggregation does it for its planes)")
+            reg.push_and_wait(slot)
+            return None                                    # (stream-ordered: nothing to wait for on the host)
         if self.exchange == "direct":
             ops = []
             for off in range(1, self.world):               # staggered peer order: rank r starts with r+1
@@ -344,6 +378,58 @@ class RowShardedAdjacency:
         return out_padded
 
 
+class _PushPeers:
+    """One exchange buffer of this rank and its counterparts on the peers (exchange="push")."""
+    RING = 1 << 12                                         # layer counters travel as values of a constant table
+
+    def __init__(self, shard, buf, group):
+        from torch.multiprocessing.reductions import reduce_tensor
+        self.shard, self.buf = shard, buf
+        dev = buf.device
+        lib = _lib.load()
+        # flags[q]: the last layer rank q's shard landed for — fine-grained device memory (gcn_exchange_flags_create)
+        fl, handle = ctypes.c_void_p(), ctypes.create_string_buffer(64)
+        with torch.cuda.device(dev):
+            _lib.check(lib.gcn_exchange_flags_create(shard.world, ctypes.cast(ctypes.byref(fl), ctypes.c_void_p),
+                                                     ctypes.cast(handle, ctypes.c_void_p)), "gcn_exchange_flags_create")
+        self.flags_ptr = fl.value
+        self.status = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.consts = torch.arange(self.RING, dtype=torch.int32, device=dev)
+        self.count = 0
+        torch.cuda.synchronize(dev)                        # (the buffer's zero fill is done before any peer may push into it)
+        handles = [None] * shard.world
+        dist.all_gather_object(handles, (reduce_tensor(buf), handle.raw), group=group)
+        self.peer_buf, self.peer_flags = [None] * shard.world, [0] * shard.world
+        for q, ((fb, ab), fh) in enumerate(handles):
+            if q == shard.rank:
+                continue
+            self.peer_buf[q] = fb(*ab)                     # the peer's buffer, mapped into this process (torch's IPC)
+            pf = ctypes.c_void_p()
+            with torch.cuda.device(dev):
+                _lib.check(lib.gcn_exchange_flags_open(ctypes.cast(ctypes.create_string_buffer(fh, 64), ctypes.c_void_p),
+                                                       ctypes.cast(ctypes.byref(pf), ctypes.c_void_p)), "gcn_exchange_flags_open")
+            self.peer_flags[q] = pf.value
+        dist.barrier(group=group)                          # every mapping exists before anyone pushes
+
+    def push_and_wait(self, slot):
+        sh, lib = self.shard, _lib.load()
+        self.count += 1
+        value = self.count % self.RING
+        st = ctypes.c_void_p(torch.cuda.current_stream(self.buf.device).cuda_stream)
+        lo = sh.rank * sh.slot_rows
+        nbytes = slot.numel() * slot.element_size()
+        vptr = ctypes.c_void_p(self.consts.data_ptr() + 4 * value)
+        for off in range(1, sh.world):                     # staggered peer order: rank r starts with r+1
+            q = (sh.rank + off) % sh.world
+            dst = self.peer_buf[q][lo: lo + sh.slot_rows]
+            _lib.check(lib.gcn_exchange_push(ctypes.c_void_p(dst.data_ptr()), ctypes.c_void_p(slot.data_ptr()), nbytes, st),
+                       "gcn_exchange_push")
+            _lib.check(lib.gcn_exchange_signal(ctypes.c_void_p(self.peer_flags[q] + 4 * sh.rank), vptr, st),
+                       "gcn_exchange_signal")
+        _lib.check(lib.gcn_exchange_wait(ctypes.c_void_p(self.flags_ptr), sh.world, sh.rank, value,
+                                         ctypes.c_void_p(self.status.data_ptr()), 20.0, st), "gcn_exchange_wait")
+
+
 class PipelinedAggregation:
     """Repeated aggregation layers H ← Â·H on a row-sharded Â with the exchange hidden.
 
@@ -356,7 +442,7 @@ class PipelinedAggregation:
     is also the kernel's preferred column tile when n·256 B fits the Infinity Cache.
     """
 
-    def __init__(self, shard, k, device, plane_cols=64, group=None, streams=None, tail_stream=False):
+    def __init__(self, shard, k, device, plane_cols=64, group=None, streams=None):
         self.shard, self.k, self.group = shard, int(k), group
         self.widths = [min(plane_cols, k - c) for c in range(0, k, plane_cols)]
         if shard.prelaid and any(w != plane_cols for w in self.widths):
@@ -364,6 +450,7 @@ class PipelinedAggregation:
         make = shard.new_prelaid_buffer if shard.prelaid else shard.new_buffer
         self.src = [make(w, device) for w in self.widths]
         self.dst = [make(w, device) for w in self.widths]
+        shard.register_exchange_buffers(self.src + self.dst, group)       # (exchange="push": peers' buffers mapped once)
         self.pending = [None] * len(self.widths)
         # One HIP stream and one operator (plan + workspaces) per plane: the planes' chains
         # (SpMM passes -> fix-up -> slice reduction -> exchange) are independent, so on separate
@@ -377,17 +464,14 @@ class PipelinedAggregation:
         # the chip and both tails (fix-up, slice reduction) end up exposed behind them, once per layer (rank share of an
         # 8-way partition: 2 x 166 us of main kernels, 390 us per layer).  With plane 0 ahead in priority its main
         # kernel takes the chip first and its tail then runs beside plane 1's main kernel (0.387 -> 0.384 ms at N = 8).
-        # tail_stream (r04): the planes' fix-up / slice-reduction passes on ONE high-priority stream of their own
-        # (CsrAdjacency.set_tail_stream), the planes' own streams at equal priority: a plane's tail is then dispatched ahead
-        # of everything else the moment its main kernel ends, beside the other plane's main kernel.
-        self.tail = torch.cuda.Stream(dev, priority=-1) if (streams and tail_stream) else None
-        self.streams = ([torch.cuda.Stream(dev, priority=(-1 if (p % 2 == 0 and self.tail is None) else 0)) for p in range(len(self.widths))]
+        # (r04: the planes' tails on ONE high-priority stream of their own, and the planes' main kernels taking turns, were built
+        #  and measured — 0.417 / 0.450 ms per layer against 0.377, profiles/r04h_sim8_tail_stream_and_turns.log: with equal
+        #  priorities the two main kernels fall into phase and both tails end up exposed behind them; with turns the cross-stream
+        #  event waits leave 31-38 us between alternate main kernels and a main kernel alone is slower than its share of two.
+        #  Removed again)
+        self.streams = ([torch.cuda.Stream(dev, priority=(-1 if p % 2 == 0 else 0)) for p in range(len(self.widths))]
                         if streams else None)
         self.locals = [shard.local] + [shard.another_local() if streams else shard.local for _ in self.widths[1:]]
-        if self.tail is not None:
-            for loc in {id(l): l for l in self.locals}.values():
-                if hasattr(loc, "set_tail_stream"):
-                    loc.set_tail_stream(self.tail)
 
     def set_local_option(self, name, *args):
         """apply a CsrAdjacency setter (set_blocks_per_cu, set_gather_width, ...) to every plane's operator"""

@@ -118,13 +118,6 @@ class CsrAdjacency:
         _lib.check(_lib.load().gcn_spmm_plan_set_blocks_per_cu(self.plan, int(blocks)),
                    "gcn_spmm_plan_set_blocks_per_cu")
 
-    def set_tail_stream(self, stream):
-        """The fix-up / slice reduction of a sliced SpMM on `stream` (a torch.cuda.Stream; None: back on the call's
-        stream) — gcn_spmm_plan_set_tail_stream.  The operator keeps a reference: the stream outlives its calls."""
-        self._tail_stream = stream
-        _lib.check(_lib.load().gcn_spmm_plan_set_tail_stream(
-            self.plan, ctypes.c_void_p(stream.cuda_stream) if stream is not None else None), "gcn_spmm_plan_set_tail_stream")
-
     def prepare_width(self, k):
         """Build now whatever a k-wide call would build at first use (gcn_spmm_plan_prepare_width): e.g. before a capture."""
         with torch.cuda.device(self.device):

@@ -129,14 +129,6 @@ int gcn_spmm_plan_set_blocks_per_cu(gcn_spmm_plan_t* plan, int32_t blocks);
  * four-per-gather kernel wherever its layout applies, whatever the row length.  Any other value:
  * GCN_ERR_INVALID_ARG. */
 int gcn_spmm_plan_set_gather_width(gcn_spmm_plan_t* plan, int32_t nz_per_gather);
-/* The passes BEHIND the main kernel of a column-sliced SpMM (fix-up, slice reduction with the epilogue) on a stream of
- * their own: main kernel on the call's stream -> event -> tail on `tail_stream` -> event -> the call's stream waits, so
- * the call keeps its meaning (everything enqueued behind it on its stream sees the finished C).  For two plans that work
- * side by side on two streams (the 64-column planes of the multi-GPU path): given a high-priority tail stream, a plan's
- * short bandwidth-bound tail runs beside the OTHER plan's main kernel instead of queueing behind it.  NULL = off
- * (default).  The stream must outlive the plan's calls; unsliced plans ignore it.  No reference counterpart
- * (flexspmm.cu:512 launches one kernel on the legacy stream). */
-int gcn_spmm_plan_set_tail_stream(gcn_spmm_plan_t* plan, void* tail_stream);
 /* number of main-kernel launches (column passes) one k-wide SpMM issues with the current tile */
 int32_t gcn_spmm_plan_num_passes(const gcn_spmm_plan_t* plan, int32_t k);
 /* name (as rocprofv3 --kernel-trace prints it, without the argument list) of the main kernel a
@@ -327,6 +319,14 @@ int gcn_order_rabbit_device(const int32_t* rowptr_dev, const int32_t* col_dev, i
 /*      (no compute units), raises one flag per peer and layer behind the      */
 /*      data, and waits for its own flags with one wave.                       */
 /* ------------------------------------------------------------------------- */
+/* `count` (<= 64) int32 flags, zeroed, in FINE-GRAINED device memory of the current device (a peer's copy engine writes
+ * them, a wave of this GPU polls them: coherent at system scope, which ordinary device memory is not promised to be),
+ * and the 64-byte IPC handle under which another process maps them (gcn_exchange_flags_open; _close unmaps, _destroy
+ * frees — after every peer has closed). */
+int gcn_exchange_flags_create(int32_t count, int32_t** flags_dev_out, void* ipc_handle_out_64);
+int gcn_exchange_flags_open(const void* ipc_handle_64, int32_t** flags_peer_out);
+int gcn_exchange_flags_close(int32_t* flags_peer);
+int gcn_exchange_flags_destroy(int32_t* flags_dev);
 /* dst_peer[0:bytes] = src[0:bytes]; dst_peer is a pointer into a peer's buffer mapped into this process; asynchronous */
 int gcn_exchange_push(void* dst_peer, const void* src, size_t bytes, void* stream);
 /* *flag_peer = *value_dev (4 bytes), enqueued behind the pushes on the same stream: "my shard has landed" */

@@ -84,8 +84,10 @@ def test_papers100m_mode_runs_a_rank_share_built_from_its_own_block():
 
 def test_two_rank_rehearsal_on_one_gpu_exchanges_and_checks_on_every_rank():
     """the N = 2 bench path end to end on ONE GPU (both ranks on cuda:0, gloo instead of RCCL): rank-local graph
-    blocks, both exchange forms, the all-reduced output check"""
-    for exchange in ("all_gather", "direct"):
+    blocks, all three exchange forms (push: the peers' buffers mapped through IPC handles, shards written by
+    hipMemcpyAsync, one flag per layer — both ranks live on the same GPU here, the mechanism is the same), the
+    all-reduced output check"""
+    for exchange in ("all_gather", "direct", "push"):
         env = dict(os.environ, GCN_AMD_BENCH_REHEARSAL="1")
         out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                               "--master-addr", "127.0.0.1", "--master-port", "29731", os.path.join(ROOT, "bench.py"),
@@ -95,6 +97,7 @@ def test_two_rank_rehearsal_on_one_gpu_exchanges_and_checks_on_every_rank():
         d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
         assert d["n_gpus"] == 2 and d["check"]["passed"] and d["config"]["ranks_seen"] == 2
         assert ("isend" in d["config"]["collective"]) == (exchange == "direct")
+        assert ("IPC" in d["config"]["collective"]) == (exchange == "push")
 
 
 def test_config5_gorder_leg_loads_an_offline_rank_for_the_cpu_generated_graph(tmp_path):
@@ -126,7 +129,7 @@ def test_config5_gorder_leg_loads_an_offline_rank_for_the_cpu_generated_graph(tm
                 os.remove(f)
 
 
-@pytest.mark.parametrize("exchange", ["all_gather", "direct"])
+@pytest.mark.parametrize("exchange", ["all_gather", "direct", "push"])
 def test_two_rank_rehearsal_with_the_prelaid_exchange_buffers(exchange):
     """the N = 2 bench path on ONE GPU at a size where the pre-laid chain switches on (slots of whole column slices, the
     exchange buffer is the next layer's scaled input): both ranks agree on the layout (one MIN all-reduce), exchange

@@ -277,34 +277,6 @@ def test_tall_narrow_operand_sliced_and_oneshot():
 
 
 # ---------------------------------------------------------------------------------------------------------------
-def test_tail_stream_gives_the_same_bits_and_keeps_the_calls_stream_order():
-    """gcn_spmm_plan_set_tail_stream: fix-up / slice reduction on a stream of their own between two events — the same
-    bits, and whatever follows the call on ITS stream still sees the finished result"""
-    n = 17000
-    rp, ci, va = sym_norm_graph(n, 1200000, seed=21)
-    d = _dev()
-    adj = _adj(rp, ci, va, n, n)
-    assert adj.num_slices >= 2 and adj.main_kernel(64).startswith("gcn::spmm_group")
-    B = torch.from_numpy(np.random.default_rng(0).standard_normal((n, 64)).astype(np.float32)).to(d)
-    C0 = adj.matmul_raw(B).clone()
-    assert rel_err(C0.cpu().numpy(), oracle_spmm(rp, ci, va, B.cpu().numpy())) <= TOL
-    tail = torch.cuda.Stream(d, priority=-1)
-    adj.set_tail_stream(tail)
-    s = torch.cuda.Stream(d)
-    torch.cuda.synchronize()
-    with torch.cuda.stream(s):
-        for _ in range(5):                              # back to back: the next main kernel must wait for the previous tail
-            C1 = adj.matmul_raw(B)
-        D = C1 * 2.0                                    # a consumer right behind the call, on the call's stream
-    s.synchronize()
-    assert torch.equal(C1, C0) and torch.equal(D, C0 * 2.0)
-    adj.set_tail_stream(None)
-    assert torch.equal(adj.matmul_raw(B), C0)
-    unsliced = _adj(rp, ci, va, n, n, slices=0)         # nothing to move: ignored
-    unsliced.set_tail_stream(tail)
-    assert rel_err(unsliced.matmul_raw(B).cpu().numpy(), C0.cpu().numpy()) <= TOL
-
-
 def test_prepare_width_builds_the_narrow_slice_set_before_the_first_call():
     """gcn_spmm_plan_prepare_width: what a k <= 32 call of an auto-sliced value-free plan builds at first use
     — the second, narrower slice set — can be built ahead (e.g. in front of a stream capture); idempotent; same results"""

@@ -7,7 +7,7 @@ set -o pipefail
 export TMPDIR=/tmp
 out=gpurun_out/${1:-weighted_ablation}
 mkdir -p $out
-for n in 0 16 32 64 80 112; do
+for n in ${ABLATIONS:-0 16 32 64 80 112}; do
   lib=""; [ $n != 0 ] && lib="artifacts/ablate/libgcnspmm_abl$n.so"
   GCN_AMD_LIB=$lib python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline > $out/bench_abl$n.json 2> $out/bench_abl$n.err || { echo "abl $n failed"; tail -3 $out/bench_abl$n.err; continue; }
   python3 - $out/bench_abl$n.json $n <<'PY'
