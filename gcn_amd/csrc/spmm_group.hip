@@ -93,7 +93,7 @@ template <int POLICY, bool VALS, bool RING, bool BIG>
 __device__ __forceinline__ void
 group_walk(const unsigned short* __restrict__ stream, const float* __restrict__ vals, const int2* __restrict__ chunk_meta,
            const float* __restrict__ Bp, float* __restrict__ Cv, float* __restrict__ P,
-           int nchunks, int T, int k, int col_tile, int ldb, int stream_nt, int blocks_per_tile, const int* __restrict__ dyn) {
+           int nchunks, int T, int k, int seg_blocks, int ldb, int stream_nt, int blocks_per_tile, const int* __restrict__ dyn) {
   // T: entries per chunk of ONE group, a multiple of 64 (a chunk is whole runs of four blocks) — a run-time value: the
   // plan picks it so that the blocks fill whole rounds of the chip on small matrices (pick_group_chunk, api_spmm.cpp)
   // dyn (drop-in flexspmm only): {buffers recognised, chunk count} written by dropin_guard_kernel — the grid was
@@ -107,9 +107,23 @@ group_walk(const unsigned short* __restrict__ stream, const float* __restrict__ 
   // One launch can cover several 64-column tiles: blocks [t*blocks_per_tile, (t+1)*blocks_per_tile) walk the whole
   // stream for tile col_tile + t.  Blocks are dispatched in index order, so the next tile starts on the CUs the
   // previous one's last blocks leave idle (blocks_per_tile % 8 == 0: a block's XCD is blockIdx % 8 either way).
-  const int tile_in_launch = (int)blockIdx.x / blocks_per_tile;
-  const int bx = (int)blockIdx.x - tile_in_launch * blocks_per_tile;
-  col_tile += tile_in_launch;
+  // Order of the (tile, block) pairs (launch_group_t says why).  seg_blocks == 0: tile-major.  seg_blocks = Q > 0: every
+  // XCD's blocks in runs of Q — run 0 for tile 0, run 0 for tile 1, ..., then run 1.  Placement only: the result is the same.
+  int tile_in_launch, bx, col_tile;
+  if (seg_blocks > 0) {
+    const int Q = seg_blocks, nbx = blocks_per_tile >> 3, tiles = (k + 63) >> 6;
+    const int x = (int)blockIdx.x & 7, i = (int)blockIdx.x >> 3;
+    const int nseg = (nbx + Q - 1) / Q, full = (nseg - 1) * tiles * Q;
+    int j;
+    if (i < full) { const int seg = i / (tiles * Q), r = i - seg * tiles * Q; tile_in_launch = r / Q; j = seg * Q + (r - tile_in_launch * Q); }
+    else { const int last = nbx - (nseg - 1) * Q, r = i - full; tile_in_launch = r / last; j = (nseg - 1) * Q + (r - tile_in_launch * last); }
+    bx = j * 8 + x;
+    col_tile = tile_in_launch;
+  } else {
+    tile_in_launch = (int)blockIdx.x / blocks_per_tile;
+    bx = (int)blockIdx.x - tile_in_launch * blocks_per_tile;
+    col_tile = tile_in_launch;
+  }
   const int c_in = ((bx >> 3) * 4 + wib) * 4;
   if (c_in >= per_xcd) return;                                  // (whole wave: per_xcd % 4 == 0)
   const int c = (bx & 7) * per_xcd + c_in + g;                  // this group's chunk
@@ -157,7 +171,7 @@ group_walk(const unsigned short* __restrict__ stream, const float* __restrict__ 
   // graph (profiles/r02zn_*); a stream that fits the caches is better left there (profiles/r02zo_*)
   u32x2_g eq = stream_nt ? __builtin_nontemporal_load(sp) : sp[0], eq_nx = eq;
   f32x4 vq = {0.f, 0.f, 0.f, 0.f}, vq_nx = vq;
-  if constexpr (VALS) { vq = stream_nt ? __builtin_nontemporal_load(vp) : vp[0]; vq_nx = vq; }
+  if constexpr (VALS) { vq = (GCN_ABLATE & 16) ? (reinterpret_cast<const f32x4*>(vals) + f)[0] : (stream_nt ? __builtin_nontemporal_load(vp) : vp[0]); vq_nx = vq; }
   unsigned fl = 0;
 #pragma unroll 1
   for (int blk = 0; blk < T / 16; ++blk) {
@@ -165,7 +179,8 @@ group_walk(const unsigned short* __restrict__ stream, const float* __restrict__ 
     if (j == 0 && blk + 4 < T / 16 && !(GCN_ABLATE & 4)) {      // the next run, a whole run ahead of its use
       const int nx = (blk / 4 + 1) * 16;
       eq_nx = stream_nt ? __builtin_nontemporal_load(sp + nx) : sp[nx];
-      if constexpr (VALS) vq_nx = (GCN_ABLATE & 16) ? vp[nx & 255] : (stream_nt ? __builtin_nontemporal_load(vp + nx) : vp[nx]);
+      if constexpr (VALS) vq_nx = (GCN_ABLATE & 16) ? (reinterpret_cast<const f32x4*>(vals) + f)[nx & 63]   /* every chunk the same 1 KiB */
+                                                    : (stream_nt ? __builtin_nontemporal_load(vp + nx) : vp[nx]);
     }
     const unsigned e = ((j & 2 ? eq.y : eq.x) >> (16 * (j & 1))) & 0xFFFFu;
     int vbits = 0;                                              // this lane's entry's value; step u takes lane u's
@@ -244,8 +259,8 @@ template <int POLICY, bool BIG>
 __global__ void __launch_bounds__(256)
 spmm_group_ring_kernel(const unsigned short* __restrict__ stream, const int2* __restrict__ chunk_meta,
                        const float* __restrict__ Bp, float* __restrict__ Cv, float* __restrict__ P,
-                       int nchunks, int T, int k, int col_tile, int ldb, int stream_nt, int blocks_per_tile, const int* __restrict__ dyn) {
-  group_walk<POLICY, false, (GCN_ABLATE & 128) == 0, BIG>(stream, nullptr, chunk_meta, Bp, Cv, P, nchunks, T, k, col_tile, ldb, stream_nt, blocks_per_tile, dyn);
+                       int nchunks, int T, int k, int seg_blocks, int ldb, int stream_nt, int blocks_per_tile, const int* __restrict__ dyn) {
+  group_walk<POLICY, false, (GCN_ABLATE & 128) == 0, BIG>(stream, nullptr, chunk_meta, Bp, Cv, P, nchunks, T, k, seg_blocks, ldb, stream_nt, blocks_per_tile, dyn);
 }
 
 // the same walk for matrices whose values do not factor: one fp32 value per entry beside the 16-bit stream,
@@ -255,9 +270,9 @@ template <int POLICY, bool BIG>
 __global__ void __launch_bounds__(256)
 spmm_group_weighted_kernel(const unsigned short* __restrict__ stream, const float* __restrict__ vals,
                            const int2* __restrict__ chunk_meta, const float* __restrict__ Bp, float* __restrict__ Cv,
-                           float* __restrict__ P, int nchunks, int T, int k, int col_tile, int ldb, int stream_nt, int blocks_per_tile,
+                           float* __restrict__ P, int nchunks, int T, int k, int seg_blocks, int ldb, int stream_nt, int blocks_per_tile,
                            const int* __restrict__ dyn) {
-  group_walk<POLICY, true, (GCN_ABLATE & 256) != 0, BIG>(stream, vals, chunk_meta, Bp, Cv, P, nchunks, T, k, col_tile, ldb, stream_nt, blocks_per_tile, dyn);
+  group_walk<POLICY, true, (GCN_ABLATE & 256) != 0, BIG>(stream, vals, chunk_meta, Bp, Cv, P, nchunks, T, k, seg_blocks, ldb, stream_nt, blocks_per_tile, dyn);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -669,10 +684,24 @@ hipError_t launch_group_t(const GroupArgs& a, int ldb, hipStream_t s) {
   const int blocks_per_tile = nblocks;
   nblocks *= tiles;
   const int2* meta = reinterpret_cast<const int2*>(a.chunk_meta);
+  // Order of the (tile, block) pairs inside the launch (r04).  Tile-major — all of tile 0, then all of tile 1 — reads the
+  // whole stream (2 bytes per entry, 6 with values) once per tile from HBM: by the time tile 1 starts, tile 0's stream has
+  // long left the 256 MiB Infinity Cache.  In SEGMENTS — every XCD's blocks cut into nseg runs, run 0 for tile 0, run 0 for
+  // tile 1, ..., then run 1 — a run's stream is read again while it still sits there.  The price is a switch of the XCD's
+  // L2-resident table slice at every run, so as few runs as keep one run's stream (all XCDs together) near half the cache:
+  // nseg = ceil(stream bytes / 120 MB); measured (profiles/r04k_*, r04l_*; Reddit-shaped, whole SpMM): value-free (230 MB)
+  // k = 128: 2.845 -> 2.680 ms at 2 runs (3 / 5 / 8 / 12 runs: 2.73 / 2.75 / 2.82 / 2.92), k = 512: 11.52 -> 10.89;
+  // weighted (689 MB) k = 128: 3.135 -> 3.043 at 6 runs (2 / 8: 3.19 / 3.08); half-size graph: value-free (57 MB) stays
+  // tile-major, weighted (172 MB) 1.452 -> 1.382 at 2.  GCN_AMD_GROUP_SEGMENTS (development) overrides nseg; 1 = tile-major.
+  static const int forced_seg = [] { const char* e = getenv("GCN_AMD_GROUP_SEGMENTS"); return e ? atoi(e) : 0; }();
+  const size_t stream_bytes = (size_t)a.nchunks * (size_t)a.T * (a.vals ? 6u : 2u);
+  const int nseg = forced_seg > 0 ? forced_seg : (int)((stream_bytes + ((size_t)120 << 20) - 1) / ((size_t)120 << 20));
+  const int nbx = blocks_per_tile / 8;
+  const int seg_blocks = (nseg > 1 && tiles > 1 && nbx > 1) ? (nbx + nseg - 1) / nseg : 0;      // 0: tile-major
   if (a.vals)
-    spmm_group_weighted_kernel<2, BIG><<<dim3(nblocks), dim3(256), 0, s>>>(a.stream, a.vals, meta, a.Bp, a.Cv, a.P, a.nchunks, a.T, a.k, 0, ldb, stream_nt, blocks_per_tile, a.dyn);
+    spmm_group_weighted_kernel<2, BIG><<<dim3(nblocks), dim3(256), 0, s>>>(a.stream, a.vals, meta, a.Bp, a.Cv, a.P, a.nchunks, a.T, a.k, seg_blocks, ldb, stream_nt, blocks_per_tile, a.dyn);
   else
-    spmm_group_ring_kernel<2, BIG><<<dim3(nblocks), dim3(256), 0, s>>>(a.stream, meta, a.Bp, a.Cv, a.P, a.nchunks, a.T, a.k, 0, ldb, stream_nt, blocks_per_tile, a.dyn);
+    spmm_group_ring_kernel<2, BIG><<<dim3(nblocks), dim3(256), 0, s>>>(a.stream, meta, a.Bp, a.Cv, a.P, a.nchunks, a.T, a.k, seg_blocks, ldb, stream_nt, blocks_per_tile, a.dyn);
   return hipGetLastError();
 }
 

@@ -197,9 +197,59 @@ def test_group_kernels_with_the_fix_up_pass_of_its_own():
     assert out.returncode == 0 and "fixup ok" in out.stdout, out.stdout[-1500:] + out.stderr[-1500:]
 
 
+def _segments_child():
+    """runs in a child process with GCN_AMD_GROUP_SEGMENTS=<runs per XCD>: the (column tile, block) order inside the merged
+    launch is placement only — prints a digest of the results of several plans and widths (incl. widths of 3-8 tiles, runs
+    that do not divide an XCD's blocks, a weighted plan); the parent compares the digests of different orders"""
+    import hashlib
+    d = torch.device("cuda:0")
+    h = hashlib.sha256()
+    for seed in (1, 4, 7, 10):
+        n, rowptr, col, val, rng = _graph(seed + 80)
+        S = int(rng.choice([2, 3, 5, 8]))
+        if seed == 7:
+            val = (val * (1.0 + 0.5 * rng.random(len(val)))).astype(np.float32)
+        adj = gcn_amd.CsrAdjacency(torch.from_numpy(rowptr).to(d), torch.from_numpy(col).to(d), torch.from_numpy(val).to(d),
+                                   (n, n), slices=S)
+        for k in (128, 192, 320, 100, 512):
+            assert adj.main_kernel(k).startswith("gcn::spmm_group"), adj.main_kernel(k)
+            B = rng.standard_normal((n, k)).astype(np.float32)
+            C = adj.matmul_raw(torch.from_numpy(B).to(d)).cpu().numpy()
+            assert rel_err(C, oracle_spmm(rowptr, col, val, B)) <= TOL, (seed, k)
+            h.update(C.tobytes())
+    from util import sym_norm_graph
+    n = 17000                                              # 37 blocks per XCD: runs of 37, 19, 13 and 6 blocks, the last one shorter
+    rowptr, col, val = sym_norm_graph(n, 1200000, seed=12)
+    adj = gcn_amd.CsrAdjacency(torch.from_numpy(rowptr).to(d), torch.from_numpy(col).to(d), torch.from_numpy(val).to(d), (n, n))
+    for k in (128, 256):
+        B = np.random.default_rng(k).standard_normal((n, k)).astype(np.float32)
+        C = adj.matmul_raw(torch.from_numpy(B).to(d)).cpu().numpy()
+        assert adj.main_kernel(k).startswith("gcn::spmm_group_ring") and rel_err(C, oracle_spmm(rowptr, col, val, B)) <= TOL
+        h.update(C.tobytes())
+    print("segments digest", h.hexdigest())
+
+
+def test_tile_order_inside_the_merged_launch_is_placement_only():
+    """GCN_AMD_GROUP_SEGMENTS = 1 (tile-major), 2, 3, 7 runs per XCD: bit-identical results (and each within 1e-5 of the
+    oracle) — the order in which a launch walks its (tile, block) pairs (spmm_group.hip, launch_group_t) never shows"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = []
+    for runs in ("1", "2", "3", "7"):
+        env = dict(os.environ, GCN_AMD_GROUP_SEGMENTS=runs, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--segments-child"], env=env, capture_output=True,
+                             text=True, timeout=600, cwd=os.path.dirname(os.path.abspath(__file__)))
+        assert out.returncode == 0 and "segments digest" in out.stdout, out.stdout[-1500:] + out.stderr[-1500:]
+        digests.append(out.stdout.split("segments digest")[1].split()[0])
+    assert len(set(digests)) == 1, digests
+
+
 if __name__ == "__main__":
     import sys
     if "--big-child" in sys.argv:
         _big_child()
     if "--fixup-child" in sys.argv:
         _fixup_child()
+    if "--segments-child" in sys.argv:
+        _segments_child()
