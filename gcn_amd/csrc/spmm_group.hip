@@ -65,8 +65,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef GCN_ABLATE
 #define GCN_ABLATE 0
 #endif
-template <int POLICY>
+#ifndef GCN_STORE_POLICY
+#define GCN_STORE_POLICY -1                          // development builds: 0 plain / 1 sc1 / 2 nt for EVERY partial-row store
+#endif
+template <int POLICY_>
 __device__ __forceinline__ void store_row_piece(float* dst, const float4& v) {
+  constexpr int POLICY = GCN_STORE_POLICY >= 0 ? GCN_STORE_POLICY : POLICY_;
   if constexpr ((GCN_ABLATE & 1) != 0) { asm volatile("" : : "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w)); return; }
   const f32x4 t = {v.x, v.y, v.z, v.w};
   if constexpr (POLICY == 1) {
