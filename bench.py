@@ -55,8 +55,8 @@ from gcn_amd.dist import PipelinedAggregation, RowShardedAdjacency   # noqa: E40
 HBM_PEAK = 8.0e12
 L2_PEAK = 34.5e12
 FABRIC_GATHER_CEILING = 8.6e12
-K_FEAT = {"reddit": 128, "products": 256, "rmat24": 512, "papers100m": 128, "reddit-dcsbm": 128}     # BASELINE.json configs 2-5 (+ the structured stand-in)
-ORDER = {"reddit": "none", "products": "rcm", "rmat24": "none", "papers100m": "none", "reddit-dcsbm": "none"}
+K_FEAT = {"reddit": 128, "products": 256, "rmat24": 512, "papers100m": 128, "reddit-dcsbm": 128, "products-dcsbm": 256}   # BASELINE.json configs 2-5 (+ the structured stand-ins)
+ORDER = {"reddit": "none", "products": "rcm", "rmat24": "none", "papers100m": "none", "reddit-dcsbm": "none", "products-dcsbm": "none"}
 TOL = 1e-5
 FULL_CHECK_MAX_N = 3_000_000      # "fp64 ... on the full matrix for n <= 3 M, on a fixed random sample of 4 096 rows otherwise"
 CPU_SAMPLE_WORK = 1.6e10          # nnz x k of the CPU-baseline sample: about 10 s per torch.spmm on the box's host
@@ -176,9 +176,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--graph", default="reddit", choices=["reddit", "products", "rmat24", "papers100m", "reddit-dcsbm"])
-    ap.add_argument("--mixing", type=float, default=0.35, help="--graph reddit-dcsbm: share of edge samples drawn across communities")
-    ap.add_argument("--communities", type=int, default=200, help="--graph reddit-dcsbm: planted communities (Zipf sizes)")
+    ap.add_argument("--graph", default="reddit", choices=["reddit", "products", "rmat24", "papers100m", "reddit-dcsbm", "products-dcsbm"])
+    ap.add_argument("--mixing", type=float, default=0.35, help="--graph *-dcsbm: share of edge samples drawn across communities")
+    ap.add_argument("--communities", type=int, default=0, help="--graph *-dcsbm: planted communities (0: 200 for reddit-, 2000 for products-)")
+    ap.add_argument("--size-skew", type=float, default=-1.0, help="--graph *-dcsbm: Zipf exponent of the community sizes (default 1.0 / 0.3)")
+    ap.add_argument("--autotune", action="store_true",
+                    help="single GPU: let CsrAdjacency.autotune() pick slices and column tile by measurement before the timed steps")
     ap.add_argument("--slices", type=int, default=-1, help="single GPU: explicit column-slice count of the plan (-1 = automatic)")
     ap.add_argument("--k", type=int, default=0, help="feature width (0 = the width BASELINE.json names for the graph)")
     ap.add_argument("--order", default="config", choices=["config", "none", "deg", "rcm", "gorder", "rabbit"],
@@ -236,13 +239,18 @@ def main():
     k = args.k or K_FEAT[args.graph]
     order = ORDER[args.graph] if args.order == "config" else args.order
     papers = args.graph == "papers100m"
-    dcsbm = args.graph == "reddit-dcsbm"
+    dcsbm = args.graph.endswith("-dcsbm")
+    if dcsbm:                              # (degree-corrected planted partitions at the reddit- / products-shaped size)
+        shape = graphgen.SHAPES[args.graph.split("-")[0]]
+        ncomm = args.communities or (200 if args.graph == "reddit-dcsbm" else 2000)
+        skew = args.size_skew if args.size_skew >= 0 else (1.0 if args.graph == "reddit-dcsbm" else 0.3)
+        maxdeg = 20000 if args.graph == "reddit-dcsbm" else 10000
     sim = args.sim_world if (world == 1 and args.sim_world > 1) else 0
     if papers and world == 1 and not sim:
         sim = 8                                              # one GPU: rank 0's share of the 8-way partition
     sharded = world > 1 or args.force_shard or sim > 1
     part_world, part_rank = (sim, 0) if sim else (world, rank)
-    if sharded and (order != "none" or args.graph in ("products", "rmat24", "reddit-dcsbm")):
+    if sharded and (order != "none" or args.graph in ("products", "rmat24") or dcsbm):
         sys.exit("bench.py: the row-sharded path runs the reddit / papers100m graphs un-renumbered")
     order_secs, order_where = 0.0, ""
 
@@ -258,8 +266,9 @@ def main():
         elif args.graph == "rmat24":
             rowptr, col, val, n = graphgen.make_rmat(args.rmat_scale, device=dev, seed=5)
         elif dcsbm:
-            rowptr, col, val, n = graphgen.make_dcsbm(n=max(16, int(232965 * args.scale)), edges=int(57307946 * args.scale),
-                                                      communities=args.communities, mixing=args.mixing, device=dev, seed=11)
+            rowptr, col, val, n = graphgen.make_dcsbm(n=max(16, int(shape["n"] * args.scale)), edges=int(shape["edges"] * args.scale),
+                                                      communities=ncomm, mixing=args.mixing, size_skew=skew, max_degree=maxdeg,
+                                                      device=dev, seed=11)
         else:
             rowptr, col, val, n = graphgen.make_graph(args.graph, device=dev, seed=1, scale=args.scale)
         if order != "none":
@@ -273,6 +282,7 @@ def main():
         adj = gcn_amd.CsrAdjacency(rowptr, col, val, (n, n), symmetric=True, chunk_nnz=args.chunk,
                                    slices="auto" if args.slices < 0 else args.slices)
         out = torch.empty((n, k), dtype=torch.float32, device=dev)
+        tuned = adj.autotune(k=k) if args.autotune else None
         adj.matmul_raw(H, out=out)                           # (the first call builds what the plan builds lazily for this width)
         torch.cuda.synchronize(dev)
         plan_secs = time.perf_counter() - t_plan
@@ -462,8 +472,8 @@ def main():
             gname = (f"papers100M-shaped R-MAT graph (graphgen.make_rmat_row_block: a,b,c,d = .57,.19,.19,.05, {PAPERS_SAMPLES} directed "
                      "samples, seed 4, labels permuted with seed 1004)")
         elif dcsbm:
-            gname = (f"Reddit-sized degree-corrected planted-partition graph (graphgen.make_dcsbm: {args.communities} communities of "
-                     f"Zipf sizes, mixing {args.mixing}, power-law degrees gamma 2.5 capped near 20 k, seed 11, labels shuffled)")
+            gname = (f"{args.graph.split('-')[0]}-sized degree-corrected planted-partition graph (graphgen.make_dcsbm: {ncomm} communities of "
+                     f"Zipf sizes (exponent {skew}), mixing {args.mixing}, power-law degrees gamma 2.5 capped near {maxdeg}, seed 11, labels shuffled)")
         elif gname is None:
             gname = (f"{args.graph}-shaped R-MAT graph (gcn_amd.graphgen.make_graph: a,b,c,d = "
                      + ",".join(f"{x:g}" for x in graphgen.SHAPES[args.graph]["abcd"]) + f", {graphgen.SHAPES[args.graph]['edges']} distinct "
@@ -547,6 +557,8 @@ def main():
             # the analogue of the reference's csr2tile (tile.cu:104-169, host, 0.53 s per 3.4 M non-zeros): CSR on the device
             # -> plan (value factors, column slices, 15-bit stream, cut lists) + the first SpMM; outside the timed steps
             line["config"]["plan_build_seconds"] = round(plan_secs, 3)
+            if tuned is not None:
+                line["config"]["autotune"] = {f"slices={s},tile={t}": round(ms, 4) for (s, t), ms in tuned.items()}
             line["config"]["ordering_ran_on"] = order_where
         if world > 1 or sim:
             # what the exchange may cost before 6x at 8 GPUs is lost: 8 ranks must finish a layer in (single-GPU step / 6)

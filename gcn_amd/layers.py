@@ -139,7 +139,7 @@ class GCN(nn.Module):
         self._ax = None
         self.output = None
         self.adj = self.features = self.labels = self.vo_mp = None
-        self.tuning = None                    # {slices: ms} measured by prepare() on a renumbered graph
+        self.tuning = None                    # {(slices, column tile): ms} measured by prepare() on a renumbered graph
         # fused-epilogue dropout: Philox keyed on (seed, offset).  The seed is drawn from torch's default generator at
         # the first training forward (so torch.manual_seed governs it like F.dropout's masks, two models or two
         # restarts differ unless seeded alike), the offset counts forward passes; both are part of state_dict-less

@@ -239,20 +239,27 @@ class CsrAdjacency:
         return out
 
     def autotune(self, k=128, reps=3, verbose=False):
-        """Measure, don't guess: time a k-wide SpMM with and without XCD column slicing on this matrix
-        and keep the faster configuration.  The automatic rule (auto_slices) is derived from unordered
-        graphs; a matrix whose rows were renumbered to sit near their neighbours (Rabbit, RCM on a graph
-        with communities) can be faster unsliced.  → dict {slices: ms}, chosen first."""
-        B = torch.randn((self.n, int(k)), dtype=torch.float32, device=self.device)
-        out = torch.empty((self.m, int(k)), dtype=torch.float32, device=self.device)
+        """Measure, don't guess: time a k-wide SpMM on this matrix in the plan shapes that can win and keep the fastest —
+        column slices {automatic, 8, none} and, unsliced and for k > 64, the column tile per pass {automatic, 64, 128}.
+        The automatic rules (auto_slices, auto_tile_cols) are derived from unordered graphs; a matrix whose rows were
+        renumbered to sit near their neighbours (Rabbit on a graph with communities) can be faster unsliced,
+        and when its table is far larger than the caches, in NARROW tiles: a community's slice of a 64-column tile fits an
+        L2 where its 256-column rows do not (products-sized planted partition, Rabbit order, k = 256: 15.8 ms with the
+        widest tile, 13.0 ms with 64-column tiles; un-renumbered: 20.1 ms, profiles/r04r_*).
+        → dict {(slices, tile_cols): ms} sorted by time; the first entry is what stays configured."""
+        k = int(k)
+        B = torch.randn((self.n, k), dtype=torch.float32, device=self.device)
+        out = torch.empty((self.m, k), dtype=torch.float32, device=self.device)
         tried = {}
-        for S in (-1, 8, 0):                                  # the automatic count, one slice per XCD, none
+        shapes = [(-1, 0), (8, 0), (0, 0)] + ([(0, 64)] if k > 64 else []) + ([(0, 128)] if k > 128 else [])
+        for S, tile in shapes:
             try:
                 self.enable_slicing(S)
+                self.set_tile_cols(tile)
             except _lib.GcnAmdError:
                 continue                                       # (unsorted rows, S*m too large, ...)
-            eff = self.num_slices
-            if eff in tried:
+            key = (self.num_slices, tile)
+            if key in tried:
                 continue
             for _i in range(2):
                 self.matmul_raw(B, out=out)
@@ -262,12 +269,13 @@ class CsrAdjacency:
                 self.matmul_raw(B, out=out)
             e1.record()
             torch.cuda.synchronize(self.device)
-            tried[eff] = e0.elapsed_time(e1) / reps
+            tried[key] = e0.elapsed_time(e1) / reps
             if verbose:
-                print(f"autotune: slices={eff}: {tried[eff]:.4f} ms")
+                print(f"autotune: slices={key[0]} tile={key[1]}: {tried[key]:.4f} ms")
         best = min(tried, key=tried.get)
-        self.enable_slicing(best)
-        self.slices = best
+        self.enable_slicing(best[0])
+        self.set_tile_cols(best[1])
+        self.slices, self.tile_cols = best
         return dict(sorted(tried.items(), key=lambda kv: kv[1]))
 
     def main_kernel(self, k, epilogue=False):

@@ -814,8 +814,8 @@ def test_autotune_keeps_the_faster_of_sliced_and_unsliced_and_the_result():
     B = graphgen.random_features(n, 128, seed=3, device="cuda:0")
     before = adj.matmul_raw(B).clone()
     timings = adj.autotune(k=128)
-    assert len(timings) >= 2 and 0 in timings and all(t > 0 for t in timings.values())
-    assert adj.num_slices == next(iter(timings))              # the fastest one stays configured
+    assert len(timings) >= 3 and (0, 0) in timings and (0, 64) in timings and all(t > 0 for t in timings.values())
+    assert adj.num_slices == next(iter(timings))[0]           # the fastest shape (slices, tile) stays configured
     after = adj.matmul_raw(B)
     assert float((after - before).abs().max() / before.abs().max()) <= 1e-6
 

@@ -49,15 +49,20 @@ def main():
     ap.add_argument("--slices", default="0,2,4,6,8,10,12")
     ap.add_argument("--rcm", action="store_true")
     ap.add_argument("--seed", type=int, default=11)
+    ap.add_argument("--shape", default="reddit", choices=["reddit", "products"],
+                    help="vertex / edge count of the graph: the Reddit-shaped headline size, or the products-shaped size of "
+                         "BASELINE config 3 (n = 2 449 029, 61.9 M edges: mean degree 51, a table far larger than the caches)")
+    ap.add_argument("--max-degree", type=int, default=20000)
+    ap.add_argument("--tiles", default="", help="also: unsliced with these column tiles per pass (64,128,256)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
-    n = int(232965 * args.scale)
-    edges = int(57307946 * args.scale)
+    n = int(graphgen.SHAPES[args.shape]["n"] * args.scale)
+    edges = int(graphgen.SHAPES[args.shape]["edges"] * args.scale)
     k = args.k
     for mix in [float(x) for x in args.mixing.split(",")]:
         rowptr, col, val, n, comm = graphgen.make_dcsbm(n=n, edges=edges, communities=args.communities, mixing=mix,
                                                         size_skew=args.size_skew, device=dev, seed=args.seed,
-                                                        return_communities=True)
+                                                        max_degree=args.max_degree, return_communities=True)
         nnz = int(col.numel())
         deg = (rowptr[1:] - rowptr[:-1]).long()
         rows = torch.repeat_interleave(torch.arange(n, device=dev), deg)
@@ -67,7 +72,7 @@ def main():
               f"mixing={mix} realised={realised:.3f} max degree={int(deg.max())} k={k}", flush=True)
         B = graphgen.random_features(n, k, seed=2, device=dev)
         out = torch.empty((n, k), device=dev)
-        res = {"graph": "reddit-dcsbm", "n": n, "nnz": nnz, "mixing": mix, "realised_mixing": round(realised, 4),
+        res = {"graph": args.shape + "-dcsbm", "n": n, "nnz": nnz, "mixing": mix, "realised_mixing": round(realised, 4),
                "communities": args.communities, "k": k, "plans": {}}
 
         base = gcn_amd.CsrAdjacency(rowptr, col, val, (n, n), symmetric=True)
@@ -93,11 +98,16 @@ def main():
             refp = ref[vomp.long()]
             print(f"  {oname}: ordering {t_order * 1e3:.1f} ms (+ CSR rewrite: {t_all * 1e3:.1f} ms) {stats}", flush=True)
             res["plans"][oname + " seconds"] = round(t_order, 4)
-            configs = [("auto", dict())] + [(f"slices={s}", dict(slices=int(s))) for s in args.slices.split(",")] + \
-                      [("panels auto", dict(panels="auto", slices=0))]
+            configs = [("auto", dict())] + [(f"slices={s}", dict(slices=int(s))) for s in args.slices.split(",") if s != ""] + \
+                      [("panels auto", dict(panels="auto", slices=0))] + \
+                      [(f"unsliced, tile={t}", dict(slices=0, _tile=int(t))) for t in args.tiles.split(",") if t != ""]
             for cname, kw in configs:
                 try:
+                    kw = dict(kw)
+                    tile = kw.pop("_tile", 0)
                     adj = gcn_amd.CsrAdjacency(rp, ci, va, (n, n), symmetric=True, **kw)
+                    if tile:
+                        adj.set_tile_cols(tile)
                     t = timed(lambda: adj.matmul_raw(Bp, out=out), args.iters)
                 except gcn_amd.GcnAmdError as e:
                     print(f"    {cname}: refused ({e})", flush=True)
