@@ -572,6 +572,7 @@ def main():
         print(json.dumps(line), flush=True)
 
     if world > 1:
+        shard.close_exchange()
         dist.destroy_process_group()
     if check_failed:
         sys.exit(f"bench.py: output check failed: rel err {rel_all} > {TOL}")

@@ -266,6 +266,13 @@ class RowShardedAdjacency:
         for buf in buffers:
             self._push[buf.data_ptr()] = _PushPeers(self, buf, group)
 
+    def close_exchange(self, group=None):
+        """exchange="push": release the IPC mappings and the flag memory (a collective: every rank calls it)"""
+        group = group if group is not None else self.group
+        for reg in self._push.values():
+            reg.close(group)
+        self._push = {}
+
     def check_exchange(self):
         """exchange="push": did a wait give up (a peer that never signalled)?  Synchronises; raises GcnAmdError."""
         for reg in self._push.values():
@@ -410,6 +417,20 @@ class _PushPeers:
                                                        ctypes.cast(ctypes.byref(pf), ctypes.c_void_p)), "gcn_exchange_flags_open")
             self.peer_flags[q] = pf.value
         dist.barrier(group=group)                          # every mapping exists before anyone pushes
+
+    def close(self, group):
+        """unmap the peers' flags, then (after a barrier: nobody writes any more) free this rank's"""
+        lib = _lib.load()
+        torch.cuda.synchronize(self.buf.device)
+        for q, pf in enumerate(self.peer_flags):
+            if pf:
+                lib.gcn_exchange_flags_close(ctypes.c_void_p(pf))
+                self.peer_flags[q] = 0
+        self.peer_buf = [None] * len(self.peer_buf)
+        dist.barrier(group=group)
+        if self.flags_ptr:
+            lib.gcn_exchange_flags_destroy(ctypes.c_void_p(self.flags_ptr))
+            self.flags_ptr = 0
 
     def push_and_wait(self, slot):
         sh, lib = self.shard, _lib.load()

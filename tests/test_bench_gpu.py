@@ -72,6 +72,24 @@ def test_config3_and_config5_modes_renumber_then_multiply_and_check(flags, order
     assert "cpu_baseline" in d and "leading" in d["cpu_baseline"]["sample"] or "full" in d["cpu_baseline"]["sample"]
 
 
+@pytest.mark.parametrize("graph,scale,k", [("reddit-dcsbm", "0.05", 128), ("products-dcsbm", "0.02", 256)])
+def test_structured_stand_ins_renumbered_by_rabbit_on_the_device_and_autotuned(graph, scale, k):
+    """round 4's degree-corrected planted partitions through bench.py at a reduced size: generated, renumbered by the parallel
+    Rabbit on the device, plan shape chosen by CsrAdjacency.autotune() (slices x column tile), EVERY output row checked against
+    fp64 (n <= 3 M), the generator's recipe in the line"""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--graph", graph, "--scale", scale, "--order", "rabbit",
+                          "--autotune", "--mixing", "0.3", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                         cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert d["check"]["passed"] and d["check"]["full_matrix"] and d["check"]["rows_per_rank"] == d["config"]["n"]
+    assert d["config"]["k"] == k and d["config"]["order"] == "rabbit" and d["config"]["ordering_seconds"] > 0
+    assert "planted-partition" in d["config"]["workload"] and "mixing 0.3" in d["config"]["workload"]
+    assert "NOT the headline config" in d["config"]["workload"]
+    tuned = d["config"]["autotune"]
+    assert len(tuned) >= 3 and "slices=0,tile=0" in tuned and "slices=0,tile=64" in tuned and min(tuned.values()) > 0
+
+
 def test_papers100m_mode_runs_a_rank_share_built_from_its_own_block():
     """BASELINE config 4 through the product path at a reduced scale: the rank is built by from_row_block from the
     block generator (the whole graph never exists), one GPU computes rank 0's share of the 8-way partition"""
