@@ -118,6 +118,22 @@ def test_two_rank_rehearsal_on_one_gpu_exchanges_and_checks_on_every_rank():
         assert ("IPC" in d["config"]["collective"]) == (exchange == "push")
 
 
+@pytest.mark.parametrize("exchange", ["push", "direct"])
+def test_four_rank_rehearsal_on_one_gpu(exchange):
+    """four ranks on ONE GPU (the box allows six processes on its card): with more than one peer the staggered peer order,
+    the per-peer flags of the push form and the slot arithmetic are no longer degenerate; pre-laid chain on"""
+    env = dict(os.environ, GCN_AMD_BENCH_REHEARSAL="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4",
+                          "--master-addr", "127.0.0.1", "--master-port", "29751", os.path.join(ROOT, "bench.py"),
+                          "--gpus", "4", "--scale", "0.25", "--steps", "3", "--warmup", "1", "--exchange", exchange],
+                         cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 4 and d["check"]["passed"] and d["check"]["rel_err"] <= 1e-5 and d["config"]["ranks_seen"] == 4
+    assert d["config"]["prelaid"] is True and d["check"]["full_matrix"]
+    assert ("IPC" in d["config"]["collective"]) == (exchange == "push")
+
+
 def test_config5_gorder_leg_loads_an_offline_rank_for_the_cpu_generated_graph(tmp_path):
     """BASELINE config 5's Gorder leg at full size uses a rank computed once, off-line (tools/gorder_rmat24.py: the host
     Gorder needs two hours at scale 24).  The same mechanism at scale 12: the tool writes rank + hashes, bench.py

@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""tools/weighted_slices_probe.py — the weighted sliced pass (values kept: gcn_spmm_plan_set_value_factors(null, null)) of the
+Reddit-shaped graph at several explicit slice counts.  Round 4: flat around the automatic 15 (10 / 12 / 13 / 14 / 15 / 16 / 17 /
+18 / 20 slices: 3.14 / 3.10 / 3.09 / 3.10 / 3.05 / 3.08 / 3.06 / 3.13 / 3.17 ms).  Development aid."""
 import sys, torch
 sys.path.insert(0, '.')
 import gcn_amd
