@@ -94,7 +94,10 @@ __device__ __forceinline__ unsigned find_root(unsigned* dest, unsigned x, unsign
 // emptying the table costs the entries, not the capacity).
 template <bool LDS>
 struct Table {
-  unsigned* key; unsigned* val; unsigned* touch; unsigned* ntouch; unsigned* dbg;
+  // touch: the slots in use, in the order they were taken (ntouch of them) — so that walking and emptying the table costs
+  // its entries, not its capacity.  LDS table: 16-bit slot numbers in LDS (r04; the walk used to sweep all 8 192 slots twice
+  // per vertex, whatever the list length); table in memory: 32-bit slot numbers in memory.
+  unsigned* key; unsigned* val; unsigned* touch; unsigned* ntouch; unsigned* dbg; unsigned short* ltouch;
   static constexpr unsigned kMask = (unsigned)(LDS ? kLdsCap : kBigCap) - 1u;
   __device__ __forceinline__ unsigned peek(unsigned i) const { return LDS ? key[i] : ld_u32(key + i); }
   __device__ __forceinline__ unsigned weight(unsigned i) const { return LDS ? val[i] : ld_u32(val + i); }
@@ -109,7 +112,8 @@ struct Table {
       if (cur == kNone) {
         const unsigned old = atomicCAS(&key[i], kNone, k);
         if (old == kNone) {
-          if (!LDS) st_u32(touch + atomicAdd(ntouch, 1u), i);
+          if (LDS) ltouch[atomicAdd(ntouch, 1u)] = (unsigned short)i;
+          else     st_u32(touch + atomicAdd(ntouch, 1u), i);
           atomicAdd(&val[i], w);
           return;
         }
@@ -166,13 +170,13 @@ __device__ __noinline__ void rabbit_vertex(const RabbitArgs& a, Table<LDS> t, un
   }
   GCN_BEAT(a, lane, 4, 0);
   __syncthreads();
-  // 4. walk the entries: best gain, number of entries.  (LDS: the whole table; memory: the slots on the touch list)
-  const unsigned nslots = LDS ? (unsigned)kLdsCap : *ntouch_lds;
+  // 4. walk the entries — the slots on the touch list: best gain, number of entries
+  const unsigned nslots = *ntouch_lds;
   double best = 0.0;
   unsigned bestv = kNone, mine = 0;
   const double du_2m = (double)du * a.two_m_inv;
   for (unsigned q = lane; q < nslots; q += 64) {
-    const unsigned i = LDS ? q : ld_u32(t.touch + q);
+    const unsigned i = LDS ? (unsigned)t.ltouch[q] : ld_u32(t.touch + q);
     const unsigned k = t.peek(i);
     if (k == kNone) continue;
     ++mine;
@@ -204,7 +208,7 @@ __device__ __noinline__ void rabbit_vertex(const RabbitArgs& a, Table<LDS> t, un
   }
   unsigned pos = incl - mine;
   for (unsigned q = lane; q < nslots; q += 64) {
-    const unsigned i = LDS ? q : ld_u32(t.touch + q);
+    const unsigned i = LDS ? (unsigned)t.ltouch[q] : ld_u32(t.touch + q);
     const unsigned k = t.peek(i);
     if (k == kNone) continue;
     if (stored) a.pool[base + pos] = ((unsigned long long)k << 32) | t.weight(i);
@@ -248,6 +252,7 @@ __device__ __noinline__ void rabbit_vertex(const RabbitArgs& a, Table<LDS> t, un
 __global__ void __launch_bounds__(64)
 rabbit_pass_kernel(RabbitArgs a) {
   __shared__ unsigned lkey[kLdsCap], lval[kLdsCap];
+  __shared__ unsigned short ltouch[kLdsCap / 2];       // (72 KiB per wave in all: two waves per CU, as before)
   __shared__ unsigned ntouch;
   const int lane = threadIdx.x;
   const int wave = blockIdx.x;
@@ -294,11 +299,11 @@ rabbit_pass_kernel(RabbitArgs a) {
         if (du != 0) atomicAdd(a.skipped, 1u);
       }
     } else if (total <= (unsigned long long)kLdsCap / 2) {
-      Table<true> t{lkey, lval, nullptr, &ntouch, a.dbg};
+      Table<true> t{lkey, lval, nullptr, &ntouch, a.dbg, ltouch};
       rabbit_vertex<true>(a, t, u, du, atom_child(au), &ntouch, lane);
     } else {
       Table<false> t{a.bkey + (size_t)wave * kBigCap, a.bval + (size_t)wave * kBigCap,
-                     a.btouch + (size_t)wave * (kBigCap / 2), &ntouch, a.dbg};
+                     a.btouch + (size_t)wave * (kBigCap / 2), &ntouch, a.dbg, nullptr};
       rabbit_vertex<false>(a, t, u, du, atom_child(au), &ntouch, lane);
     }
     GCN_BEAT(a, lane, 9, 0);

@@ -125,7 +125,7 @@ def test_four_rank_rehearsal_on_one_gpu(exchange):
     env = dict(os.environ, GCN_AMD_BENCH_REHEARSAL="1")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4",
                           "--master-addr", "127.0.0.1", "--master-port", "29751", os.path.join(ROOT, "bench.py"),
-                          "--gpus", "4", "--scale", "0.25", "--steps", "3", "--warmup", "1", "--exchange", exchange],
+                          "--gpus", "4", "--scale", "0.12", "--steps", "2", "--warmup", "1", "--exchange", exchange],
                          cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])

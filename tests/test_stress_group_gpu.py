@@ -110,7 +110,7 @@ def test_group12_kernel_random(seed):
                                (n, n), slices=S)
     assert adj.num_slices == S and adj.has_value_factors
     name = adj.main_kernel(k)
-    knobs_off = os.environ.get("GCN_AMD_GROUP12", "1") == "0"
+    knobs_off = os.environ.get("GCN_AMD_GROUP12", "1") == "0" or os.environ.get("GCN_AMD_GROUP_BIG", "0") == "1"   # (64-bit slice bases: the 64-column pass)
     if len(col) // n >= 48 and not knobs_off:                    # (below: the weighted pass, see valless_pays)
         assert name == "gcn::spmm_group12_kernel", (name, k)
     assert name.startswith("gcn::spmm_group"), (name, k)
