@@ -28,7 +28,8 @@ extern "C" {
 /* ------------------------------------------------------------------------- */
 /* status codes (native API).  The reference has no error convention at all   */
 /* (void functions, cuspmm.cu:3-21 only prints) — the drop-in symbols keep    */
-/* `void`, print to stderr and abort() on a HIP failure so it is never silent.*/
+/* `void`, print ONE line to stderr and return with the caller's outputs      */
+/* untouched (section (2) below): never silent, never fatal.                  */
 /* ------------------------------------------------------------------------- */
 #define GCN_OK                 0
 #define GCN_ERR_INVALID_ARG    1
