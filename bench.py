@@ -207,6 +207,9 @@ def main():
                          "instead of writing the next layer's pre-laid input in the epilogue")
     ap.add_argument("--no-plane-streams", action="store_true",
                     help="debug: N > 1 / --sim-world: all column planes on one stream (default: one stream per plane)")
+    ap.add_argument("--plane-cols", type=int, default=64,
+                    help="debug: N > 1 / --sim-world: columns per plane (64: two planes pipeline their exchanges under each other's "
+                         "SpMM; 128: ONE plane, one launch whose tiles re-read the stream from the Infinity Cache, one exchange behind it)")
     ap.add_argument("--sim-world", type=int, default=0,
                     help="debug: on ONE GPU, time rank 0's row block of a W-way partition (compute only, "
                          "no collective) — a rehearsal of the per-rank work at N = W, not a metric")
@@ -307,12 +310,12 @@ def main():
                 args.graph, part_world, part_rank, device=dev, seed=1, scale=args.scale)
         shard = RowShardedAdjacency.from_row_block(lrp, lcol, lval, bounds, part_rank, part_world, make_local,
                                                    value_factor=u, total_nnz=nnz, exchange=args.exchange,
-                                                   prelaid=False if args.no_prelaid else "auto")
+                                                   prelaid=False if args.no_prelaid else "auto", plane_cols=args.plane_cols)
         del lcol, u
         if sim:
             shard.collective = False
         # column planes of 64: the exchange of one plane overlaps the SpMM of the next
-        pipe = PipelinedAggregation(shard, k, dev, plane_cols=64, streams=False if args.no_plane_streams else None)
+        pipe = PipelinedAggregation(shard, k, dev, plane_cols=args.plane_cols, streams=False if args.no_plane_streams else None)
 
         def fill(p, buf):                 # features exist in the exchange layout only: every rank fills ITS rows,
             g = torch.Generator(device=dev)   # one exchange assembles the layer input
@@ -410,7 +413,7 @@ def main():
     # ---- roofline of the dominant kernel (the plan's main kernel), this rank's launches ---------
     # (N = 1: one timed interval per SpMM = all column passes of the main kernel; N > 1: one per
     #  64-column plane SpMM of this rank's row block)
-    kp = k if not sharded else min(k, 64)                 # columns per timed SpMM
+    kp = k if not sharded else min(k, args.plane_cols)    # columns per timed SpMM
     passes = local_adj.num_passes(kp)                     # main-kernel launches per timed SpMM
     spmm_avg = sum(kernel_ms) / max(len(kernel_ms), 1) * 1e-3
     kavg = spmm_avg / passes                              # per LAUNCH, what rocprofv3 --stats averages

@@ -480,7 +480,16 @@ class PipelinedAggregation:
         # 0.501 ms per layer, profiles/r01f_sim8_streams.log).  Off on the CPU (gloo tests) and for a single plane.
         dev = torch.device(device)
         if streams is None:
-            streams = dev.type == "cuda" and len(self.widths) > 1
+            # ... when a plane's main kernel is SHORT.  A kernel of many rounds of blocks fills the chip by itself and only
+            # loses by sharing it; one of fewer than ~2.5 rounds leaves its last round half empty, which a second plane's
+            # kernel fills (r04, rank shares of the Reddit-shaped graph, one stream / two streams: N = 2 (6.8 rounds) 1.371 /
+            # 1.464 ms, N = 4 (3.4) 0.713 / 0.760, N = 8 (1.7) 0.402 / 0.380; profiles/r04z_rank_share_plane_streams.log).
+            # On one stream the planes still pipeline: plane 0's exchange runs under plane 1's SpMM.
+            rounds = 0.0
+            if dev.type == "cuda":
+                cu = int(_lib.load().gcn_device_cu_count())
+                rounds = shard.local_nnz / 8192.0 / (4.0 * max(cu, 1))      # blocks of 16 chunks x 512 entries, 4 resident per CU
+            streams = dev.type == "cuda" and len(self.widths) > 1 and rounds < 2.5
         # Staggered priorities: two chains of equal length started together stay in phase — both main kernels share
         # the chip and both tails (fix-up, slice reduction) end up exposed behind them, once per layer (rank share of an
         # 8-way partition: 2 x 166 us of main kernels, 390 us per layer).  With plane 0 ahead in priority its main
