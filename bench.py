@@ -568,7 +568,7 @@ def main():
             line["scaling_budget"] = {
                 "layer_ms_this_run": round(elapsed / args.steps * 1e3, 4),
                 "note": "a 6x aggregate at N = 8 needs (rank share + unhidden exchange) <= ms_per_step(N = 1) / 6; "
-                        "ms_per_step(N = 1) is the driver's own N = 1 run (2.86 ms in round 2 -> 0.477 ms)",
+                        "ms_per_step(N = 1) is the driver's own N = 1 run (2.66-2.70 ms in round 4 -> 0.443-0.450 ms)",
             }
         if not sharded and not args.no_cpu_baseline and not check_failed:
             line["cpu_baseline"] = cpu_baseline(rowptr, col, val, n, k, H, args.graph)
