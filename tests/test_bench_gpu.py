@@ -163,6 +163,22 @@ def test_config5_gorder_leg_loads_an_offline_rank_for_the_cpu_generated_graph(tm
                 os.remove(f)
 
 
+@pytest.mark.parametrize("exchange", ["all_gather", "push"])
+def test_two_rank_rehearsal_with_both_planes_on_one_stream(exchange):
+    """what PipelinedAggregation chooses by itself when a plane's main kernel is long (a rank of 2 or 4 of the headline
+    graph): both planes on ONE stream, the exchange of plane 0 (asynchronous collective, or pushes + flag wait on the
+    stream) under the SpMM of plane 1 — forced here on a small graph"""
+    env = dict(os.environ, GCN_AMD_BENCH_REHEARSAL="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29761", os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--scale", "0.12", "--steps", "3", "--warmup", "1", "--exchange", exchange,
+                          "--no-plane-streams"], cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["check"]["passed"] and d["check"]["rel_err"] <= 1e-5
+    assert d["config"]["prelaid"] is True and d["roofline"]["concurrent_planes"] == 1
+
+
 @pytest.mark.parametrize("exchange", ["all_gather", "direct", "push"])
 def test_two_rank_rehearsal_with_the_prelaid_exchange_buffers(exchange):
     """the N = 2 bench path on ONE GPU at a size where the pre-laid chain switches on (slots of whole column slices, the
