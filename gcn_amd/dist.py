@@ -489,7 +489,11 @@ class PipelinedAggregation:
             if dev.type == "cuda":
                 cu = int(_lib.load().gcn_device_cu_count())
                 rounds = shard.local_nnz / 8192.0 / (4.0 * max(cu, 1))      # blocks of 16 chunks x 512 entries, 4 resident per CU
-            streams = dev.type == "cuda" and len(self.widths) > 1 and rounds < 2.5
+            # (Only for the sliced group kernels that rule was measured on — the pre-laid chain: the unsliced, HBM-bound
+            #  kernel of a papers100M-shaped block does gain from a second plane beside it, 29.4-30.0 ms per layer on two
+            #  streams against 31.3 on one, profiles/r04z_*.)
+            long_kernels = bool(getattr(shard, "prelaid", False)) and rounds >= 2.5
+            streams = dev.type == "cuda" and len(self.widths) > 1 and not long_kernels
         # Staggered priorities: two chains of equal length started together stay in phase — both main kernels share
         # the chip and both tails (fix-up, slice reduction) end up exposed behind them, once per layer (rank share of an
         # 8-way partition: 2 x 166 us of main kernels, 390 us per layer).  With plane 0 ahead in priority its main
