@@ -1,4 +1,4 @@
-// Internal interface between the C-ABI layer (api.cpp) and the device code
+// Internal interface between the C-ABI layer (plan_policy.cpp, plan_build.cpp, api_spmm.cpp, api_dropin.cpp) and the device code
 // (spmm_kernels.hip).  Not installed; the public contract is include/gcn_spmm.h.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -19,7 +19,7 @@ struct SpmmArgs {
   int relu;
   int nchunks, T, m, nnz, k;
   int n = 0x7fffffff;      // rows of B (columns of A); decides 32-bit buffer addressing
-  int ldb = 0;             // row stride of B in floats, 0 = k (api.cpp pads rows to 128-byte lines for odd k)
+  int ldb = 0;             // row stride of B in floats, 0 = k (api_spmm.cpp pads rows to 128-byte lines for odd k)
   // drop-in mode (flexspmm symbol): nnz is only known on the device (nnz_dev =
   // &rowptr[m]); the kernels then derive nchunks and the value pointer themselves
   // and the host sizes its grids with the upper bound nchunks_grid.

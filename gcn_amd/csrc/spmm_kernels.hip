@@ -111,7 +111,7 @@ spmm_chunk_kernel(const int* __restrict__ g_rowptr, const int* __restrict__ g_co
                   const int* __restrict__ g_nnz_dev,
                   int relu, int nchunks, int T, int m, int nnz, int kk, int col_tile, int accumulate, int ldb) {
   // drop-in (flexspmm) mode: the host does not know nnz; it lives in rowptr[m] and
-  // the values follow the column indices in one buffer (api.cpp, csr2tile layout)
+  // the values follow the column indices in one buffer (api_dropin.cpp, csr2tile layout)
   if (g_nnz_dev) {
     nnz = *g_nnz_dev;
     nchunks = (int)(((long long)nnz + T - 1) / T);

@@ -69,7 +69,7 @@ __device__ __forceinline__ float4 quad_reduce(float4 t) {
 // widths are bound by L2 requests per non-zero, not by instructions — so it is not instantiated.)
 // VALLESS: the matrix values are not read at all — every stored entry counts 1.  For adjacencies whose
 // values factor as u[r]*u[c] (the GCN normalisation D^-1/2 (A+I) D^-1/2) the caller pre-scales B's rows by
-// u and scales the finished rows by u[r] (api.cpp, slice_reduce_kernel): the 4-byte value stream is
+// u and scales the finished rows by u[r] (api_spmm.cpp, slice_reduce_kernel): the 4-byte value stream is
 // 5 % of what the sliced kernel moves across the fabric, and fabric bytes are its time.
 // COL16 (value-free pass only): the column stream is 16 bits per non-zero — the column's offset inside its
 // slice (slices <= 65 535 columns wide).  The slice-major stream is laid out so that no chunk straddles two
