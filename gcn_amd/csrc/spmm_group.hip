@@ -99,7 +99,7 @@ group_walk(const unsigned short* __restrict__ stream, const float* __restrict__ 
            const float* __restrict__ Bp, float* __restrict__ Cv, float* __restrict__ P,
            int nchunks, int T, int k, int seg_blocks, int ldb, int stream_nt, int blocks_per_tile, const int* __restrict__ dyn) {
   // T: entries per chunk of ONE group, a multiple of 64 (a chunk is whole runs of four blocks) — a run-time value: the
-  // plan picks it so that the blocks fill whole rounds of the chip on small matrices (pick_group_chunk, api_spmm.cpp)
+  // plan picks it so that the blocks fill whole rounds of the chip on small matrices (group_chunk, plan_policy.cpp)
   // dyn (drop-in flexspmm only): {buffers recognised, chunk count} written by dropin_guard_kernel — the grid was
   // sized from an upper bound of the chunk count, and buffers this library did not pack are not walked at all
   if (dyn) { if (dyn[0] == 0) return; nchunks = dyn[1]; }
